@@ -1,0 +1,105 @@
+"""ctypes binding of libgcd_amd.so (the C ABI declared in include/gcd_amd.h).
+
+The library is the product: there is no Python/CPU fallback.  If the shared object is missing or a
+call fails, this module raises — loudly — instead of computing the result some other way.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libgcd_amd.so"
+
+ABI_VERSION = 1
+
+# GEMM modes / output kinds (mirror include/gcd_amd.h)
+GEMM_PLAIN, GEMM_CONV3X3, GEMM_TEMPORAL3 = 0, 1, 2
+OUT_F32, OUT_F16, OUT_GEGLU = 0, 1, 2
+
+
+class GcdError(RuntimeError):
+    """A libgcd_amd entry point returned a non-zero status."""
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("W", C.c_void_p), ("out", C.c_void_p),
+        ("lda", C.c_int64), ("ldo", C.c_int64),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("mode", C.c_int32),
+        ("Cin", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("Ho", C.c_int32),
+        ("Wo", C.c_int32), ("stride", C.c_int32), ("upsample", C.c_int32), ("T", C.c_int32),
+        ("HW", C.c_int32),
+        ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("ld_rowvec", C.c_int64),
+        ("rows_per_vec", C.c_int32),
+        ("R1", C.c_void_p), ("ldr1", C.c_int64), ("R2", C.c_void_p), ("ldr2", C.c_int64),
+        ("s_acc", C.c_float), ("s_r1", C.c_float), ("s_r2", C.c_float),
+        ("frame_alpha", C.c_void_p), ("rows_per_alpha", C.c_int32), ("r1_blend", C.c_int32),
+        ("out_kind", C.c_int32), ("zero_page", C.c_void_p),
+    ]
+
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); every symbol include/gcd_amd.h declares
+SIGNATURES = {
+    "gcd_abi_version": (_i, []),
+    "gcd_last_error": (C.c_char_p, []),
+    "gcd_device_info": (_i, [_i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(C.c_size_t)]),
+    "gcd_gemm_f16": (_i, [C.POINTER(GemmDesc), _vp]),
+    "gcd_linear_smallm_f32": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "gcd_groupnorm_stats": (_i, [_vp, _i64, _i, _vp, _i64, _i, _i64, _i64, _f, _vp, _i, _vp, _vp]),
+    "gcd_groupnorm_apply": (_i, [_vp, _i64, _i, _vp, _i64, _i, _i64, _i64, _vp, _vp, _vp, _i, _vp,
+                                 _i64, _vp, _i64, _vp]),
+    "gcd_layernorm_f16": (_i, [_vp, _i64, _i64, _i, _vp, _vp, _f, _vp, _i64, _i, _vp, _i64, _vp,
+                               _i64, _vp]),
+    "gcd_attn_transpose_v": (_i, [_vp, _i64, _i, _i, _i, _vp, _i, _vp]),
+    "gcd_attn_spatial_f16": (_i, [_vp, _i64, _vp, _i, _vp, _i64, _i, _i, _i, _vp]),
+    "gcd_attn_temporal_f16": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "gcd_pack_input": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp]),
+    "gcd_unpack_output": (_i, [_vp, _i64, _vp, _i, _i, _i, _vp]),
+    "gcd_cast_f32_f16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),
+    "gcd_cfg_euler_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _vp]),
+    "gcd_edm_scalings": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "gcd_timestep_embedding": (_i, [_vp, _vp, _i, _i, _f, _vp]),
+    "gcd_graph_begin_capture": (_i, [_vp]),
+    "gcd_graph_end_capture": (_i, [_vp, C.POINTER(_vp)]),
+    "gcd_graph_launch": (_i, [_vp, _vp]),
+    "gcd_graph_destroy": (_i, [_vp]),
+    "gcd_event_create": (_i, [C.POINTER(_vp)]),
+    "gcd_event_record": (_i, [_vp, _vp]),
+    "gcd_event_sync": (_i, [_vp]),
+    "gcd_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(_f)]),
+    "gcd_event_destroy": (_i, [_vp]),
+    "gcd_stream_sync": (_i, [_vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libgcd_amd.so (once).  Raises if it has not been built — never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise GcdError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. "
+            "Run `python -m gcd_amd.csrc.build` (needs hipcc); gcd_amd has no CPU fallback."
+        )
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.gcd_abi_version()
+    if v != ABI_VERSION:
+        raise GcdError(f"libgcd_amd ABI version {v} != expected {ABI_VERSION}; rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().gcd_last_error().decode(errors="replace")
+        raise GcdError(f"{what or 'libgcd_amd call'} failed (status {rc}): {msg}")

@@ -1,0 +1,347 @@
+// attention.hip — self-attention kernels of the SVD VideoUNet for gfx950 (head dim 64, fp16
+// operands, fp32 softmax / accumulation).
+//
+//  * gcd_attn_spatial_f16: flash-style attention over the H*W tokens of one frame (sequence up to
+//    9216), 19.4 % of the step's FLOPs.  4 waves x 32 queries per workgroup,
+//    64-key K / V^T tiles staged with LDS-DMA into swizzled LDS (double-buffered, one barrier per
+//    tile).  QK^T is computed *swapped* (S^T = K Q^T, v_mfma_f32_32x32x16_f16) so that a lane owns
+//    one query column: the row max / row sum are in-register reductions plus ONE cross-half shuffle,
+//    and the exponentiated tile is already laid out as the B operand of O^T += V^T P^T — the key
+//    order (r&3) + 8(r>>2) + 4(lane>>5) of the accumulator registers is reused as the MFMA k-slot
+//    order and V^T is fetched from LDS with the matching pattern, so P never moves between lanes.
+//  * gcd_attn_transpose_v: builds the V^T[head][d][token] operand (zero padded to 64 keys).
+//  * gcd_attn_temporal_f16: attention over the T <= 16 frames of one pixel; 0.05 % of the FLOPs and
+//    HBM-bound, so it runs on the VALU (v_dot2_f32_f16 / v_fma_mix) with 16 lanes per problem.
+#include "common.h"
+
+#define LOG2E_F 1.4426950408889634f
+
+// ------------------------------------------------------------------------------------------------
+// V transpose: qkv[(f*S+s)*ld + 2C + h*64 + d] -> vt[((f*heads+h)*64 + d)*S_pad + s]
+// grid (S_pad/64, heads, frames), block 256
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_transpose_v_kernel(const f16* __restrict__ qkv,
+                                                               int64_t ld, int S, int heads,
+                                                               f16* __restrict__ vt, int S_pad) {
+  __shared__ __attribute__((aligned(16))) f16 tile[64][72];
+  const int t = threadIdx.x;
+  const int s0 = blockIdx.x * 64, h = blockIdx.y, f = blockIdx.z;
+  const int C = heads * 64;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = i * 256 + t;
+    const int tok = p >> 3, ch = p & 7;
+    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (s0 + tok < S) v = *(const f16x8*)(qkv + ((int64_t)f * S + s0 + tok) * ld + 2 * C + h * 64 + ch * 8);
+    *(f16x8*)(&tile[tok][ch * 8]) = v;
+  }
+  __syncthreads();
+  const int d = t >> 2, tg = (t & 3) * 16;
+  f16x8 o0, o1;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    o0[e] = tile[tg + e][d];
+    o1[e] = tile[tg + 8 + e][d];
+  }
+  f16* dst = vt + (((int64_t)f * heads + h) * 64 + d) * S_pad + s0 + tg;
+  *(f16x8*)dst = o0;
+  *(f16x8*)(dst + 8) = o1;
+}
+
+extern "C" int gcd_attn_transpose_v(const void* qkv, int64_t ld, int frames, int S, int heads,
+                                    void* vt, int S_pad, void* stream) {
+  GCD_CHECK_ARG(qkv && vt, "gcd_attn_transpose_v: null pointer");
+  GCD_CHECK_ARG(frames > 0 && S > 0 && heads > 0, "gcd_attn_transpose_v: empty problem");
+  GCD_CHECK_ARG(S_pad % 64 == 0 && S_pad >= S, "gcd_attn_transpose_v: S_pad=%d for S=%d", S_pad, S);
+  GCD_CHECK_ARG(ld % 8 == 0 && ld >= 3 * heads * 64, "gcd_attn_transpose_v: ld=%lld", (long long)ld);
+  GCD_CHECK_ARG(frames <= 65535 && heads <= 65535, "gcd_attn_transpose_v: grid too large");
+  hipLaunchKernelGGL(attn_transpose_v_kernel, dim3(S_pad / 64, heads, frames), dim3(256), 0,
+                     (hipStream_t)stream, (const f16*)qkv, ld, S, heads, (f16*)vt, S_pad);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Spatial flash attention.  grid (ceil(S/128), heads, frames), block 256.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restrict__ qkv,
+                                                              int64_t ld, const f16* __restrict__ vt,
+                                                              int S_pad, f16* __restrict__ out,
+                                                              int64_t ldo, int S, int heads,
+                                                              float c /* scale * log2(e) */) {
+  // stage = [K tile 64 keys x 64 d | V^T tile 64 d x 64 keys], 8 KB each, two stages
+  __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int head = blockIdx.y, frame = blockIdx.z;
+  const int C = heads * 64;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+
+  // Q^T fragments (B operand): query l31, d = 16 ks + 8 half + j
+  f16x8 qf[4];
+  {
+    int qi = q0 + l31;
+    qi = qi < S ? qi : S - 1;
+    const f16* qp = qkv + ((int64_t)frame * S + qi) * ld + head * 64 + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const f16x8*)(qp + ks * 16);
+  }
+
+  // staging bookkeeping: piece p = i*256 + t -> row i*32 + (t>>3), physical chunk t&7
+  const int prow = t >> 3;
+  const int cl = (t & 7) ^ ((prow >> 1) & 7);
+  const f16* kbase = qkv + (int64_t)frame * S * ld + C + head * 64 + cl * 8;
+  const f16* vbase = vt + (((int64_t)frame * heads + head) * 64) * S_pad + cl * 8;
+
+  auto stage = [&](int kv0, int buf) {
+    char* Ks = smem + buf * 16384;
+    char* Vs = Ks + 8192;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = prow + 32 * i;
+      int key = kv0 + row;
+      key = key < S ? key : S - 1;
+      glds16(kbase + (int64_t)key * ld, Ks + (i * 256 + wave * 64) * 16);
+      glds16(vbase + (int64_t)row * S_pad + kv0, Vs + (i * 256 + wave * 64) * 16);
+    }
+  };
+
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles = (S + 63) >> 6;
+  stage(0, 0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int buf = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < ntiles) stage((kt + 1) << 6, buf ^ 1);
+    const char* Ks = smem + buf * 16384;
+    const char* Vs = Ks + 8192;
+
+    // ---- S^T = K Q^T : two 32-key sub-tiles ----
+    f32x16 s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const f16x8 k0 = *(const f16x8*)(Ks + lds_tile_off(l31, 2 * ks + half));
+      const f16x8 k1 = *(const f16x8*)(Ks + lds_tile_off(32 + l31, 2 * ks + half));
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[ks], s1, 0, 0, 0);
+    }
+    // register r of a sub-tile holds key (r&3) + 8*(r>>2) + 4*half
+    if ((kt << 6) + 64 > S) {
+      const int kb = (kt << 6) + 4 * half;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb + (r & 3) + 8 * (r >> 2);
+        if (key >= S) s0[r] = -INFINITY;
+        if (key + 32 >= S) s1[r] = -INFINITY;
+      }
+    }
+    // ---- online softmax (per query = per lane column) ----
+    float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    m_run = m_new;
+    const float mc = m_new * c;
+    float psum = 0.f;
+    f16x8 pf[4];  // pf[2*kt2 + s] = P^T fragment (B operand) for k-step s of sub-tile kt2
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));
+      const float p1 = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc));
+      psum += p0 + p1;
+      pf[r >> 3][r & 7] = (f16)p0;
+      pf[2 + (r >> 3)][r & 7] = (f16)p1;
+    }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o0[r] *= alpha;
+      o1[r] *= alpha;
+    }
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int ch = 4 * kt2 + 2 * s;
+        f16x8 a0, a1;
+        {
+          const f16x4 lo = *(const f16x4*)(Vs + lds_tile_off(l31, ch) + 8 * half);
+          const f16x4 hi = *(const f16x4*)(Vs + lds_tile_off(l31, ch + 1) + 8 * half);
+          a0 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        {
+          const f16x4 lo = *(const f16x4*)(Vs + lds_tile_off(32 + l31, ch) + 8 * half);
+          const f16x4 hi = *(const f16x4*)(Vs + lds_tile_off(32 + l31, ch + 1) + 8 * half);
+          a1 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, pf[2 * kt2 + s], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, pf[2 * kt2 + s], o1, 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- normalise and store: o{0,1}[r] is O[query l31][d = 32 dt + (r&3) + 8 (r>>2) + 4 half] ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  const int qi = q0 + l31;
+  if (qi < S) {
+    f16* op = out + ((int64_t)frame * S + qi) * ldo + head * 64 + 4 * half;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f16x4 v0, v1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v0[e] = (f16)(o0[4 * g + e] * inv);
+        v1[e] = (f16)(o1[4 * g + e] * inv);
+      }
+      *(f16x4*)(op + 8 * g) = v0;
+      *(f16x4*)(op + 32 + 8 * g) = v1;
+    }
+  }
+}
+
+extern "C" int gcd_attn_spatial_f16(const void* qkv, int64_t ld, const void* vt, int S_pad,
+                                    void* out, int64_t ldo, int frames, int S, int heads,
+                                    void* stream) {
+  GCD_CHECK_ARG(qkv && vt && out, "gcd_attn_spatial_f16: null pointer");
+  GCD_CHECK_ARG(frames > 0 && S > 0 && heads > 0, "gcd_attn_spatial_f16: empty problem");
+  GCD_CHECK_ARG(S_pad % 64 == 0 && S_pad >= S, "gcd_attn_spatial_f16: S_pad=%d for S=%d", S_pad, S);
+  GCD_CHECK_ARG(ld % 8 == 0 && ld >= 3 * heads * 64 && ldo % 4 == 0 && ldo >= heads * 64,
+                "gcd_attn_spatial_f16: ld=%lld ldo=%lld", (long long)ld, (long long)ldo);
+  GCD_CHECK_ARG(frames <= 65535 && heads <= 65535, "gcd_attn_spatial_f16: grid too large");
+  const float c = 0.125f * LOG2E_F;  // head dim 64 -> scale 1/8
+  hipLaunchKernelGGL(attn_spatial_kernel, dim3((S + 127) / 128, heads, frames), dim3(256), 0,
+                     (hipStream_t)stream, (const f16*)qkv, ld, (const f16*)vt, S_pad, (f16*)out, ldo,
+                     S, heads, c);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Temporal attention: one (clip, pixel, head) problem per 16 lanes; lane i owns query frame i.
+// ------------------------------------------------------------------------------------------------
+#define TPROB 16                     // problems per workgroup
+#define TP_STRIDE(T) ((T) * 128 + 16)  // bytes per problem in LDS (+16: spread problems over banks)
+
+__global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restrict__ qkv, int64_t ld,
+                                                            f16* __restrict__ out, int64_t ldo,
+                                                            int64_t nprob, int T, int HW, int heads) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x;
+  const int p = t >> 4, i = t & 15;
+  const int pstride = TP_STRIDE(T);
+  char* Kp = smem + p * pstride;
+  char* Vp = smem + TPROB * pstride + p * pstride;
+  const int64_t pid = (int64_t)blockIdx.x * TPROB + p;
+  const bool valid = pid < nprob && i < T;
+  const int C = heads * 64;
+  int h = 0;
+  int64_t row = 0;
+  if (valid) {
+    h = (int)(pid % heads);
+    const int64_t ps = pid / heads;
+    const int s = (int)(ps % HW);
+    const int64_t b = ps / HW;
+    row = (b * T + i) * HW + s;
+  }
+  f16x8 q[8];
+  if (valid) {
+    const f16* src = qkv + row * ld + h * 64;
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      q[cc] = *(const f16x8*)(src + cc * 8);
+      *(f16x8*)(Kp + i * 128 + cc * 16) = *(const f16x8*)(src + C + cc * 8);
+      *(f16x8*)(Vp + i * 128 + cc * 16) = *(const f16x8*)(src + 2 * C + cc * 8);
+    }
+  } else {
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) q[cc] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  __syncthreads();
+  if (!valid) return;
+
+  float sc[16];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    sc[j] = -INFINITY;
+    if (j < T) {
+      float a = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) {
+        const f16x8 kk = *(const f16x8*)(Kp + j * 128 + cc * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          a = __builtin_amdgcn_fdot2((f16x2){q[cc][2 * e], q[cc][2 * e + 1]},
+                                     (f16x2){kk[2 * e], kk[2 * e + 1]}, a, false);
+      }
+      sc[j] = a * 0.125f;
+      mx = fmaxf(mx, sc[j]);
+    }
+  }
+  float l = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float e = (j < T) ? __expf(sc[j] - mx) : 0.f;
+    sc[j] = e;
+    l += e;
+  }
+  const float inv = 1.0f / l;
+  float o[64];
+#pragma unroll
+  for (int d = 0; d < 64; ++d) o[d] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (j < T) {
+      const float pj = sc[j] * inv;
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) {
+        const f16x8 vv = *(const f16x8*)(Vp + j * 128 + cc * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[cc * 8 + e] = fmaf(pj, (float)vv[e], o[cc * 8 + e]);
+      }
+    }
+  }
+  f16* dst = out + row * ldo + h * 64;
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc) {
+    f16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (f16)o[cc * 8 + e];
+    *(f16x8*)(dst + cc * 8) = v;
+  }
+}
+
+extern "C" int gcd_attn_temporal_f16(const void* qkv, int64_t ld, void* out, int64_t ldo, int clips,
+                                     int T, int HW, int heads, void* stream) {
+  GCD_CHECK_ARG(qkv && out, "gcd_attn_temporal_f16: null pointer");
+  GCD_CHECK_ARG(clips > 0 && HW > 0 && heads > 0, "gcd_attn_temporal_f16: empty problem");
+  GCD_CHECK_ARG(T >= 1 && T <= 16, "gcd_attn_temporal_f16: T=%d (supported: 1..16 frames)", T);
+  GCD_CHECK_ARG(ld % 8 == 0 && ld >= 3 * heads * 64 && ldo % 8 == 0 && ldo >= heads * 64,
+                "gcd_attn_temporal_f16: ld=%lld ldo=%lld", (long long)ld, (long long)ldo);
+  const int64_t nprob = (int64_t)clips * HW * heads;
+  const int64_t blocks = (nprob + TPROB - 1) / TPROB;
+  GCD_CHECK_ARG(blocks < (1ll << 31), "gcd_attn_temporal_f16: grid too large");
+  const int smem = 2 * TPROB * TP_STRIDE(T);
+  static bool attr_set = false;
+  if (!attr_set) {
+    GCD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_temporal_kernel,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      2 * TPROB * TP_STRIDE(16)));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attn_temporal_kernel, dim3((unsigned)blocks), dim3(256), smem,
+                     (hipStream_t)stream, (const f16*)qkv, ld, (f16*)out, ldo, nprob, T, HW, heads);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,74 @@
+"""Build libgcd_amd.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+Usage: python -m gcd_amd.csrc.build [--force] [--save-temps]
+The shared object lands next to the package (gcd_amd/libgcd_amd.so) so that it travels with the
+source tree to the GPU box (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent
+PKG = CSRC.parent
+ROOT = PKG.parent
+LIB = PKG / "libgcd_amd.so"
+STAMP = PKG / ".libgcd_amd.stamp"
+SOURCES = ["runtime.hip", "gemm.hip", "norm.hip", "attention.hip", "elementwise.hip"]
+HEADERS = [CSRC / "common.h", ROOT / "include" / "gcd_amd.h"]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+         "-ffp-contract=fast"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, PATH and /opt/rocm/bin/hipcc)")
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for p in [CSRC / s for s in SOURCES] + HEADERS:
+        h.update(p.read_bytes())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -> Path:
+    digest = _digest()
+    if not force and LIB.exists() and STAMP.exists() and STAMP.read_text().strip() == digest:
+        return LIB
+    hipcc = _hipcc()
+    objdir = CSRC / "build"
+    objdir.mkdir(exist_ok=True)
+    procs = []
+    for src in SOURCES:
+        obj = objdir / (src + ".o")
+        cmd = [hipcc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+        if save_temps:
+            cmd.insert(1, "-save-temps=obj")
+        if verbose:
+            print("[gcd_amd.build]", " ".join(cmd), flush=True)
+        procs.append((src, obj, subprocess.Popen(cmd, cwd=str(objdir))))
+    objs = []
+    for src, obj, pr in procs:
+        if pr.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+        objs.append(str(obj))
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", str(LIB)]
+    if verbose:
+        print("[gcd_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    STAMP.write_text(digest)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv)
+    print(LIB)

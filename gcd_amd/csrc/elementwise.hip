@@ -1,0 +1,281 @@
+// elementwise.hip — the small kernels around the contractions: tiny per-frame MLPs (fp32), input
+// packing / output unpacking between the reference's NCHW fp32 boundary and the token-major device
+// layout, casts, and the fused CFG + denoiser-affine + Euler update of the sampler.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// y[M,N] = [y +] act_out( act_in(x[M,K]) @ W[N,K]^T + b )   fp32, M <= 32.
+// Workgroup = 4 waves, 16 output columns (4 per wave).  x is staged (activation applied) through
+// LDS in K chunks of 256; lane = (m = lane & 31, k-half = lane >> 5) so that the only cross-lane
+// step is one xor-32 add.  Weight reads are wave-broadcast (L2-resident, 100s of KB per layer).
+// ------------------------------------------------------------------------------------------------
+#define SM_KC 256
+#define SM_LDX (SM_KC + 4)
+
+__global__ __launch_bounds__(256) void linear_smallm_kernel(const float* __restrict__ x, int64_t ldx,
+                                                            const float* __restrict__ W,
+                                                            const float* __restrict__ b,
+                                                            float* __restrict__ y, int64_t ldy, int M,
+                                                            int N, int K, int flags) {
+  __shared__ __attribute__((aligned(16))) float xs[32 * SM_LDX];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int m = lane & 31, kh = lane >> 5;
+  const int n0 = blockIdx.x * 16 + wave * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int kc = 0; kc < K; kc += SM_KC) {
+    // stage x[:, kc:kc+256] (zero padded) with the input activation applied
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = t + 256 * i;
+      const int mm = idx >> 6, kv = (idx & 63) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (mm < M && kc + kv < K) {
+        v = *(const f32x4*)(x + (int64_t)mm * ldx + kc + kv);
+        if (flags & 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+        }
+      }
+      *(f32x4*)(xs + mm * SM_LDX + kv) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn) {
+      const int n = n0 + nn;
+      if (n < N) {
+        const float* wr = W + (int64_t)n * K + kc + kh * 128;
+        const float* xr = xs + m * SM_LDX + kh * 128;
+        float a = acc[nn];
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
+          if (kc + kh * 128 + i * 4 < K) {
+            const f32x4 wv = *(const f32x4*)(wr + i * 4);
+            const f32x4 xv = *(const f32x4*)(xr + i * 4);
+            a = fmaf(xv[0], wv[0], a);
+            a = fmaf(xv[1], wv[1], a);
+            a = fmaf(xv[2], wv[2], a);
+            a = fmaf(xv[3], wv[3], a);
+          }
+        }
+        acc[nn] = a;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int nn = 0; nn < 4; ++nn) {
+    const float tot = acc[nn] + __shfl_xor(acc[nn], 32);
+    const int n = n0 + nn;
+    if (kh == 0 && m < M && n < N) {
+      float v = tot + (b ? b[n] : 0.f);
+      if (flags & 2) v = silu_f(v);
+      float* dst = y + (int64_t)m * ldy + n;
+      if (flags & 4) v += *dst;
+      *dst = v;
+    }
+  }
+}
+
+extern "C" int gcd_linear_smallm_f32(const float* x, int64_t ldx, const float* W, const float* b,
+                                     float* y, int64_t ldy, int M, int N, int K, int act_flags,
+                                     void* stream) {
+  GCD_CHECK_ARG(x && W && y, "gcd_linear_smallm_f32: null pointer");
+  GCD_CHECK_ARG(M >= 1 && M <= 32, "gcd_linear_smallm_f32: M=%d (supported 1..32)", M);
+  GCD_CHECK_ARG(N >= 1 && K >= 4 && K % 4 == 0 && ldx % 4 == 0,
+                "gcd_linear_smallm_f32: N=%d K=%d ldx=%lld (K, ldx must be multiples of 4)", N, K,
+                (long long)ldx);
+  hipLaunchKernelGGL(linear_smallm_kernel, dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, x,
+                     ldx, W, b, y, ldy, M, N, K, act_flags);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// NCHW fp32 -> token-major fp16 with per-frame c_in scaling, CFG duplication and channel concat.
+// out16[(n*HW + p)*Cpad + c]: c < Cx: x[n % nx][c][p] * c_in[n]; Cx <= c < Cx+Cc: concat[n][c-Cx][p];
+// rest 0 (padding up to the GEMM's 64-channel K granule).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x, int nx, int Cx,
+                                                         const float* __restrict__ cc, int Cc,
+                                                         const float* __restrict__ c_in, int N,
+                                                         int HW, f16* __restrict__ out, int Cpad) {
+  const int64_t total = (int64_t)N * HW;
+  const int nvec = Cpad >> 3;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * 256) {
+    const int n = (int)(idx / HW);
+    const int p = (int)(idx - (int64_t)n * HW);
+    const float ci = c_in ? c_in[n] : 1.0f;
+    const float* xs = x + (int64_t)(n % nx) * Cx * HW + p;
+    const float* cs = cc ? cc + (int64_t)n * Cc * HW + p : nullptr;
+    f16* dst = out + idx * Cpad;
+    for (int v = 0; v < nvec; ++v) {
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = v * 8 + e;
+        float val = 0.f;
+        if (c < Cx) val = xs[(int64_t)c * HW] * ci;
+        else if (c < Cx + Cc) val = cs[(int64_t)(c - Cx) * HW];
+        o[e] = (f16)val;
+      }
+      *(f16x8*)(dst + v * 8) = o;
+    }
+  }
+}
+
+extern "C" int gcd_pack_input(const float* x, int nx, int Cx, const float* concat, int Cc,
+                              const float* c_in, int N, int HW, void* out16, int Cpad,
+                              void* stream) {
+  GCD_CHECK_ARG(x && out16, "gcd_pack_input: null pointer");
+  GCD_CHECK_ARG(nx > 0 && N > 0 && N % nx == 0 && HW > 0, "gcd_pack_input: N=%d nx=%d HW=%d", N, nx,
+                HW);
+  GCD_CHECK_ARG(Cc == 0 || concat, "gcd_pack_input: concat null with Cc=%d", Cc);
+  GCD_CHECK_ARG(Cpad % 8 == 0 && Cpad >= Cx + Cc, "gcd_pack_input: Cpad=%d < %d", Cpad, Cx + Cc);
+  int64_t blocks = ((int64_t)N * HW + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
+                     nx, Cx, concat, Cc, c_in, N, HW, (f16*)out16, Cpad);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
+// token-major fp32 [N*HW, ld] (first Cout channels) -> NCHW fp32 [N, Cout, HW]
+__global__ __launch_bounds__(256) void unpack_output_kernel(const float* __restrict__ in, int64_t ld,
+                                                            float* __restrict__ out, int Cout, int N,
+                                                            int HW) {
+  const int64_t total = (int64_t)N * HW;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * 256) {
+    const int n = (int)(idx / HW);
+    const int p = (int)(idx - (int64_t)n * HW);
+    for (int c = 0; c < Cout; ++c) out[((int64_t)n * Cout + c) * HW + p] = in[idx * ld + c];
+  }
+}
+
+extern "C" int gcd_unpack_output(const float* in, int64_t ld, float* out, int Cout, int N, int HW,
+                                 void* stream) {
+  GCD_CHECK_ARG(in && out, "gcd_unpack_output: null pointer");
+  GCD_CHECK_ARG(Cout > 0 && N > 0 && HW > 0 && ld >= Cout, "gcd_unpack_output: bad geometry");
+  int64_t blocks = ((int64_t)N * HW + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(unpack_output_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     in, ld, out, Cout, N, HW);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
+// fp32 [M, C] (ld) -> fp16 [M, C] (ld), C % 8 == 0
+__global__ __launch_bounds__(256) void cast_f32_f16_kernel(const float* __restrict__ x, int64_t ldx,
+                                                           f16* __restrict__ y, int64_t ldy,
+                                                           int64_t M, int C) {
+  const int cv8 = C >> 3;
+  const int64_t total = M * cv8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx / cv8;
+    const int c = (int)(idx - r * cv8) * 8;
+    const f32x4 a = *(const f32x4*)(x + r * ldx + c), b = *(const f32x4*)(x + r * ldx + c + 4);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = (f16)a[e];
+      o[e + 4] = (f16)b[e];
+    }
+    *(f16x8*)(y + r * ldy + c) = o;
+  }
+}
+
+extern "C" int gcd_cast_f32_f16(const float* x, int64_t ldx, void* y16, int64_t ldy, int64_t M, int C,
+                                void* stream) {
+  GCD_CHECK_ARG(x && y16, "gcd_cast_f32_f16: null pointer");
+  GCD_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0 && ldx % 4 == 0 && ldy % 8 == 0,
+                "gcd_cast_f32_f16: M=%lld C=%d ldx=%lld ldy=%lld", (long long)M, C, (long long)ldx,
+                (long long)ldy);
+  int64_t blocks = (M * (C / 8) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(cast_f32_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     x, ldx, (f16*)y16, ldy, M, C);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sampler kernels
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cfg_euler_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ net,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ sig,
+                                                        float* __restrict__ xo, int nx, int T,
+                                                        int64_t chw) {
+  const float sigma = sig[0], sigma_next = sig[1];
+  const float s2 = sigma * sigma + 1.0f;
+  const float c_skip = 1.0f / s2;
+  const float c_out = -sigma / sqrtf(s2);
+  const float dt = sigma_next - sigma;
+  const int64_t total = (int64_t)nx * chw;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * 256) {
+    const int n = (int)(idx / chw);
+    const float xv = x[idx];
+    const float du = net[idx] * c_out + xv * c_skip;
+    const float dc = net[idx + total] * c_out + xv * c_skip;
+    const float den = du + scale[n % T] * (dc - du);
+    const float d = (xv - den) / sigma;
+    xo[idx] = xv + dt * d;
+  }
+}
+
+extern "C" int gcd_cfg_euler_step(const float* x, const float* net, const float* scale,
+                                  const float* sig, float* x_out, int nx, int T, int64_t chw,
+                                  void* stream) {
+  GCD_CHECK_ARG(x && net && scale && sig && x_out, "gcd_cfg_euler_step: null pointer");
+  GCD_CHECK_ARG(nx > 0 && T > 0 && chw > 0, "gcd_cfg_euler_step: empty problem");
+  int64_t blocks = ((int64_t)nx * chw + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(cfg_euler_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
+                     net, scale, sig, x_out, nx, T, chw);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
+__global__ void edm_scalings_kernel(const float* __restrict__ sig, float* __restrict__ c_in,
+                                    float* __restrict__ c_noise, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float s = sig[0];
+  c_in[n] = 1.0f / sqrtf(s * s + 1.0f);
+  c_noise[n] = 0.25f * logf(s);
+}
+
+extern "C" int gcd_edm_scalings(const float* sig, float* c_in, float* c_noise, int N, void* stream) {
+  GCD_CHECK_ARG(sig && c_in && c_noise && N > 0, "gcd_edm_scalings: bad arguments");
+  hipLaunchKernelGGL(edm_scalings_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, sig,
+                     c_in, c_noise, N);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, float* __restrict__ emb, int N,
+                                          int dim, float max_period) {
+  const int half = dim / 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * half) return;
+  const int n = idx / half, k = idx - n * half;
+  const float f = expf(-logf(max_period) * (float)k / (float)half);
+  const float a = t[n] * f;
+  emb[(int64_t)n * dim + k] = cosf(a);
+  emb[(int64_t)n * dim + half + k] = sinf(a);
+  if ((dim & 1) && k == 0) emb[(int64_t)n * dim + dim - 1] = 0.f;
+}
+
+extern "C" int gcd_timestep_embedding(const float* t, float* emb, int N, int dim, float max_period,
+                                      void* stream) {
+  GCD_CHECK_ARG(t && emb && N > 0 && dim >= 2, "gcd_timestep_embedding: bad arguments");
+  const int total = N * (dim / 2);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, t, emb, N, dim, max_period);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}

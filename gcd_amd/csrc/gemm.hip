@@ -1,0 +1,385 @@
+// gemm.hip — fp16 x fp16 -> fp32 MFMA GEMM family for gfx950 (MI355X).
+//
+// One kernel template serves every contraction of the VideoUNet forward (81 % of the step's
+// FLOPs): nn.Linear, Conv2d 3x3 (stride 1/2, optional fused nearest-x2 upsample),
+// Conv2d 1x1 and the (3,1,1) temporal Conv3d, all as (implicit) GEMMs over token-major fp16
+// activations:   out[m, n] = epilogue( sum_k A(m, k) * W[n, k] ).
+//
+// CDNA4 mapping
+//   * 256-thread workgroup = 4 waves (2x2), block tile BM x BN (128x128 or 128x160 — every channel
+//     count of the SVD UNet is a multiple of 320, so 160 divides all N), K step 64.
+//   * A and W tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip).
+//     The LDS image is lane-linear, so the bank swizzle is applied to the per-lane *source* chunk
+//     and undone with the same XOR on the ds_read_b128 side (lds_tile_off).
+//   * The A address generator is the implicit-GEMM gather: each lane owns BM/32 tile rows for the
+//     whole K loop and re-derives (tap, dy, dx | dt) only when the K step crosses a tap boundary;
+//     out-of-image taps read a device zero page instead of branching around the DMA.
+//   * v_mfma_f32_16x16x32_f16 with the operands swapped (W is the "A" operand): the accumulator
+//     layout then gives every lane 4 consecutive output channels of one token, so bias, residual
+//     and output accesses are 16-byte vectors.
+//   * Double-buffered LDS, one barrier per K step: wait(tile k) -> barrier -> issue DMA(tile k+1)
+//     -> MFMA(tile k).
+//   * blockIdx -> tile mapping is XCD-aware: the 8 XCDs each own a contiguous range of tiles and
+//     sweep N fastest, so an A row-panel is fetched from HBM once and re-read from that XCD's L2.
+//   * Epilogue fuses bias, per-frame vectors (timestep embedding / collapsed 1-key cross-attention),
+//     up to two fp32 residual streams with AlphaBlender scaling, GEGLU, and the fp16 down-cast.
+#include "common.h"
+
+struct GemmK {
+  const f16* A;
+  const f16* W;
+  void* out;
+  int64_t lda, ldo;
+  int M, N, K;
+  int Cin, Hi, Wi, Ho, Wo, stride, up, T, HW;
+  const float* bias;
+  const float* rowvec;
+  int64_t ld_rowvec;
+  int rows_per_vec;
+  const float* R1;
+  int64_t ldr1;
+  const float* R2;
+  int64_t ldr2;
+  float s_acc, s_r1, s_r2;
+  const float* frame_alpha;
+  int rows_per_alpha;
+  int r1_blend;
+  int out_kind;
+  const f16* zero;
+  int tiles_m, tiles_n;
+};
+
+template <int BM, int BN, int WM, int WN, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmK p) {
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+  constexpr int A_ROUNDS = BM / 32, W_ROUNDS = BN / 32;
+  constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE_BYTES = A_BYTES + W_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // ---- XCD-aware tile assignment (bijective for any grid size) ----
+  int tile_m, tile_n;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tile_m = L / p.tiles_n;
+    tile_n = L - tile_m * p.tiles_n;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- per-thread staging bookkeeping ----
+  const int prow = t >> 3;                              // tile row within a staging round
+  const int cl = (t & 7) ^ ((prow >> 1) & 7);           // logical 16-B chunk this lane fetches
+
+  int64_t a_off[A_ROUNDS];   // PLAIN: element offset of the row; conv modes: see below
+  int a_y[A_ROUNDS], a_x[A_ROUNDS];
+  bool a_ok[A_ROUNDS];
+#pragma unroll
+  for (int i = 0; i < A_ROUNDS; ++i) {
+    const int m = m0 + prow + 32 * i;
+    a_ok[i] = m < p.M;
+    if (MODE == GCD_GEMM_PLAIN) {
+      const int mc = a_ok[i] ? m : p.M - 1;
+      a_off[i] = (int64_t)mc * p.lda + cl * 8;
+      a_y[i] = a_x[i] = 0;
+    } else if (MODE == GCD_GEMM_CONV3X3) {
+      const int hw = p.Ho * p.Wo;
+      const int n = m / hw;
+      const int rem = m - n * hw;
+      a_y[i] = rem / p.Wo;
+      a_x[i] = rem - a_y[i] * p.Wo;
+      a_off[i] = (int64_t)n * p.Hi * p.Wi;              // frame base, in pixels
+    } else {  // TEMPORAL3
+      const int fr = m / p.HW;
+      a_y[i] = fr % p.T;                                 // frame index within its clip
+      a_x[i] = 0;
+      a_off[i] = (int64_t)m;                             // row index
+    }
+  }
+  int64_t w_off[W_ROUNDS];
+#pragma unroll
+  for (int i = 0; i < W_ROUNDS; ++i) {
+    int n = n0 + prow + 32 * i;
+    n = n < p.N ? n : p.N - 1;
+    w_off[i] = (int64_t)n * p.K + cl * 8;
+  }
+
+  // K-step state for the conv address generators (block-uniform)
+  int tap = 0, c0 = 0;
+
+  auto stage = [&](int k0, int buf) {
+    char* As = smem + buf * STAGE_BYTES;
+    char* Ws = As + A_BYTES;
+    int dy = 0, dx = 0;
+    if (MODE == GCD_GEMM_CONV3X3) {
+      dy = tap / 3 - 1;
+      dx = tap - (tap / 3) * 3 - 1;
+    } else if (MODE == GCD_GEMM_TEMPORAL3) {
+      dy = tap - 1;
+    }
+#pragma unroll
+    for (int i = 0; i < A_ROUNDS; ++i) {
+      const f16* src;
+      if (MODE == GCD_GEMM_PLAIN) {
+        src = p.A + a_off[i] + k0;
+      } else if (MODE == GCD_GEMM_CONV3X3) {
+        int iy, ix;
+        bool ok = a_ok[i];
+        if (p.up) {
+          const int uy = a_y[i] + dy, ux = a_x[i] + dx;
+          ok = ok && uy >= 0 && uy < p.Ho && ux >= 0 && ux < p.Wo;
+          iy = uy >> 1;
+          ix = ux >> 1;
+        } else {
+          iy = a_y[i] * p.stride + dy;
+          ix = a_x[i] * p.stride + dx;
+          ok = ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        }
+        src = ok ? p.A + (a_off[i] + (int64_t)iy * p.Wi + ix) * p.lda + c0 + cl * 8
+                 : p.zero + cl * 8;
+      } else {
+        const int tt = a_y[i] + dy;
+        const bool ok = a_ok[i] && tt >= 0 && tt < p.T;
+        src = ok ? p.A + (a_off[i] + (int64_t)dy * p.HW) * p.lda + c0 + cl * 8 : p.zero + cl * 8;
+      }
+      glds16(src, As + (i * 256 + wave * 64) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < W_ROUNDS; ++i) glds16(p.W + w_off[i] + k0, Ws + (i * 256 + wave * 64) * 16);
+    // advance the tap state to the next K step
+    if (MODE != GCD_GEMM_PLAIN) {
+      c0 += 64;
+      if (c0 >= p.Cin) {
+        c0 = 0;
+        ++tap;
+      }
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K >> 6;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my DMA pieces of tile kt have landed
+    __syncthreads();                                    // ... and everybody else's; tile kt-1 is consumed
+    if (kt + 1 < nk) stage((kt + 1) << 6, buf ^ 1);
+    const char* As = smem + buf * STAGE_BYTES;
+    const char* Ws = As + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int chunk = ks * 4 + (lane >> 4);
+      f16x8 af[TM], wf[TN];
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+        af[j] = *(const f16x8*)(As + lds_tile_off(wm * WM + j * 16 + (lane & 15), chunk));
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+        wf[i] = *(const f16x8*)(Ws + lds_tile_off(wn * WN + i * 16 + (lane & 15), chunk));
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane holds out[m][nb .. nb+3] for (i = n-tile, j = m-tile) ----
+  const int nq = (lane >> 4) * 4;
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int m = m0 + wm * WM + j * 16 + (lane & 15);
+    if (m >= p.M) continue;
+    float sa = p.s_acc, sr1 = p.s_r1, sr2 = p.s_r2;
+    if (p.frame_alpha) {
+      const float al = p.frame_alpha[m / p.rows_per_alpha];
+      sa = 1.0f - al;
+      sr2 = al;
+      if (p.r1_blend) sr1 *= 1.0f - al;
+    }
+    const float* rv = p.rowvec ? p.rowvec + (int64_t)(m / p.rows_per_vec) * p.ld_rowvec : nullptr;
+    if (p.out_kind == GCD_OUT_GEGLU) {
+      if constexpr ((TN % 2) == 0) {
+#pragma unroll
+        for (int i = 0; i < TN; i += 2) {
+          const int nt = n0 + wn * WN + i * 16;      // value rows nt.., gate rows nt+16..
+          if (nt >= p.N) continue;
+          f32x4 a = acc[i][j], g = acc[i + 1][j];
+          if (p.bias) {
+            a += *(const f32x4*)(p.bias + nt + nq);
+            g += *(const f32x4*)(p.bias + nt + 16 + nq);
+          }
+          f16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (f16)(a[r] * gelu_f(g[r]));
+          *(f16x4*)((f16*)p.out + (int64_t)m * p.ldo + (nt >> 1) + nq) = o;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int nb = n0 + wn * WN + i * 16;
+        if (nb >= p.N) continue;
+        const int n = nb + nq;
+        f32x4 v = acc[i][j];
+        if (p.bias) v += *(const f32x4*)(p.bias + n);
+        if (rv) v += *(const f32x4*)(rv + n);
+        v *= sa;
+        if (p.R1) v += sr1 * *(const f32x4*)(p.R1 + (int64_t)m * p.ldr1 + n);
+        if (p.R2) v += sr2 * *(const f32x4*)(p.R2 + (int64_t)m * p.ldr2 + n);
+        if (p.out_kind == GCD_OUT_F32) {
+          *(f32x4*)((float*)p.out + (int64_t)m * p.ldo + n) = v;
+        } else {
+          f16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (f16)v[r];
+          *(f16x4*)((f16*)p.out + (int64_t)m * p.ldo + n) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int MODE>
+static int launch_gemm(const GemmK& k, hipStream_t s) {
+  constexpr int smem = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  auto fn = gemm_f16_kernel<BM, BN, WM, WN, MODE>;
+  if (!attr_set) {
+    GCD_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      smem));
+    attr_set = true;
+  }
+  GemmK kk = k;
+  kk.tiles_m = (k.M + BM - 1) / BM;
+  kk.tiles_n = (k.N + BN - 1) / BN;
+  const int64_t nblk = (int64_t)kk.tiles_m * kk.tiles_n;
+  GCD_CHECK_ARG(nblk > 0 && nblk < (1ll << 31), "gcd_gemm_f16: bad grid %lld", (long long)nblk);
+  hipLaunchKernelGGL(fn, dim3((unsigned)nblk), dim3(256), smem, s, kk);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int MODE>
+static int dispatch_tile(const GemmK& k, hipStream_t s) {
+  bool use160;
+  if (k.out_kind == GCD_OUT_GEGLU) {
+    use160 = false;
+  } else {
+    const int pad128 = (k.N + 127) / 128 * 128, pad160 = (k.N + 159) / 160 * 160;
+    use160 = pad160 <= pad128;
+  }
+  if (use160) return launch_gemm<128, 160, 64, 80, MODE>(k, s);
+  return launch_gemm<128, 128, 64, 64, MODE>(k, s);
+}
+
+extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
+  GCD_CHECK_ARG(d != nullptr, "gcd_gemm_f16: null descriptor");
+  GCD_CHECK_ARG(d->A && d->W && d->out, "gcd_gemm_f16: null operand");
+  GCD_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "gcd_gemm_f16: empty problem M=%d N=%d K=%d",
+                d->M, d->N, d->K);
+  GCD_CHECK_ARG(d->K % 64 == 0, "gcd_gemm_f16: K=%d must be a multiple of 64", d->K);
+  GCD_CHECK_ARG(d->N % 16 == 0, "gcd_gemm_f16: N=%d must be a multiple of 16", d->N);
+  GCD_CHECK_ARG(d->lda % 8 == 0, "gcd_gemm_f16: lda=%lld must be a multiple of 8 (16-B rows)",
+                (long long)d->lda);
+  GCD_CHECK_ARG(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->W & 15) == 0 &&
+                    ((uintptr_t)d->out & 15) == 0,
+                "gcd_gemm_f16: operands must be 16-byte aligned");
+  GCD_CHECK_ARG(d->out_kind >= GCD_OUT_F32 && d->out_kind <= GCD_OUT_GEGLU,
+                "gcd_gemm_f16: bad out_kind %d", d->out_kind);
+  if (d->out_kind == GCD_OUT_GEGLU) {
+    GCD_CHECK_ARG(d->N % 32 == 0, "gcd_gemm_f16: GEGLU needs N %% 32 == 0 (N=%d)", d->N);
+    GCD_CHECK_ARG(!d->R1 && !d->R2 && !d->rowvec, "gcd_gemm_f16: GEGLU takes bias only");
+    GCD_CHECK_ARG(d->ldo % 4 == 0, "gcd_gemm_f16: ldo must be a multiple of 4");
+  } else {
+    GCD_CHECK_ARG(d->ldo % 4 == 0, "gcd_gemm_f16: ldo must be a multiple of 4");
+  }
+  if (d->rowvec)
+    GCD_CHECK_ARG(d->rows_per_vec > 0 && d->ld_rowvec % 4 == 0, "gcd_gemm_f16: bad rowvec geometry");
+  if (d->R1) GCD_CHECK_ARG(d->ldr1 % 4 == 0, "gcd_gemm_f16: ldr1 must be a multiple of 4");
+  if (d->R2) GCD_CHECK_ARG(d->ldr2 % 4 == 0, "gcd_gemm_f16: ldr2 must be a multiple of 4");
+  if (d->frame_alpha) GCD_CHECK_ARG(d->rows_per_alpha > 0, "gcd_gemm_f16: rows_per_alpha <= 0");
+
+  GemmK k;
+  k.A = (const f16*)d->A;
+  k.W = (const f16*)d->W;
+  k.out = d->out;
+  k.lda = d->lda;
+  k.ldo = d->ldo;
+  k.M = d->M;
+  k.N = d->N;
+  k.K = d->K;
+  k.Cin = d->Cin;
+  k.Hi = d->Hi;
+  k.Wi = d->Wi;
+  k.Ho = d->Ho;
+  k.Wo = d->Wo;
+  k.stride = d->stride;
+  k.up = d->upsample;
+  k.T = d->T;
+  k.HW = d->HW;
+  k.bias = d->bias;
+  k.rowvec = d->rowvec;
+  k.ld_rowvec = d->ld_rowvec;
+  k.rows_per_vec = d->rows_per_vec;
+  k.R1 = d->R1;
+  k.ldr1 = d->ldr1;
+  k.R2 = d->R2;
+  k.ldr2 = d->ldr2;
+  k.s_acc = d->s_acc;
+  k.s_r1 = d->s_r1;
+  k.s_r2 = d->s_r2;
+  k.frame_alpha = d->frame_alpha;
+  k.rows_per_alpha = d->rows_per_alpha;
+  k.r1_blend = d->r1_blend;
+  k.out_kind = d->out_kind;
+  k.zero = (const f16*)d->zero_page;
+  k.tiles_m = k.tiles_n = 0;
+  hipStream_t s = (hipStream_t)stream;
+
+  switch (d->mode) {
+    case GCD_GEMM_PLAIN:
+      return dispatch_tile<GCD_GEMM_PLAIN>(k, s);
+    case GCD_GEMM_CONV3X3: {
+      GCD_CHECK_ARG(d->zero_page, "gcd_gemm_f16: conv mode needs a zero page");
+      GCD_CHECK_ARG(d->Cin > 0 && d->Cin % 64 == 0 && d->K == 9 * d->Cin,
+                    "gcd_gemm_f16: conv3x3 needs Cin %% 64 == 0 and K == 9*Cin (Cin=%d K=%d)",
+                    d->Cin, d->K);
+      GCD_CHECK_ARG(d->stride == 1 || d->stride == 2, "gcd_gemm_f16: stride %d", d->stride);
+      GCD_CHECK_ARG(d->Ho > 0 && d->Wo > 0 && d->M % (d->Ho * d->Wo) == 0,
+                    "gcd_gemm_f16: M=%d is not frames*Ho*Wo (%dx%d)", d->M, d->Ho, d->Wo);
+      if (d->upsample)
+        GCD_CHECK_ARG(d->stride == 1 && d->Ho == 2 * d->Hi && d->Wo == 2 * d->Wi,
+                      "gcd_gemm_f16: fused upsample needs Ho=2Hi, Wo=2Wi, stride 1");
+      else
+        GCD_CHECK_ARG(d->Ho == (d->Hi - 1) / d->stride + 1 && d->Wo == (d->Wi - 1) / d->stride + 1,
+                      "gcd_gemm_f16: conv3x3 pad-1 geometry mismatch (%dx%d -> %dx%d, stride %d)",
+                      d->Hi, d->Wi, d->Ho, d->Wo, d->stride);
+      return dispatch_tile<GCD_GEMM_CONV3X3>(k, s);
+    }
+    case GCD_GEMM_TEMPORAL3: {
+      GCD_CHECK_ARG(d->zero_page, "gcd_gemm_f16: temporal mode needs a zero page");
+      GCD_CHECK_ARG(d->Cin > 0 && d->Cin % 64 == 0 && d->K == 3 * d->Cin,
+                    "gcd_gemm_f16: temporal3 needs Cin %% 64 == 0 and K == 3*Cin");
+      GCD_CHECK_ARG(d->T > 0 && d->HW > 0 && d->M % (d->T * d->HW) == 0,
+                    "gcd_gemm_f16: M=%d is not clips*T*HW (T=%d HW=%d)", d->M, d->T, d->HW);
+      return dispatch_tile<GCD_GEMM_TEMPORAL3>(k, s);
+    }
+    default:
+      gcd_set_error("gcd_gemm_f16: unknown mode %d", d->mode);
+      return 2;
+  }
+}

@@ -1,0 +1,305 @@
+// norm.hip — GroupNorm(32) and LayerNorm over the fp32 token-major residual stream (gfx950).
+//
+// These are the HBM-bound kernels of the VideoUNet forward (4.36 G GroupNorm
+// elements + 5.09 G LayerNorm elements per step).  Design rules used here:
+//   * every global access is a 16-byte vector (float4 in, 4 x fp16 = 8 B or 8 x fp16 = 16 B out);
+//   * statistics are accumulated in fp64 per lane and reduced with wavefront shuffles + LDS, so
+//     E[x^2] - mean^2 is safe for 1.3 M-element groups (time_stack GroupNorm over T*H*W);
+//   * GroupNorm reads a *virtual concat* [x1 | x2] so the decoder's torch.cat (video_model.py:524)
+//     never materialises in fp32; the fp16 operand it feeds to the next conv is written once,
+//     normalised + SiLU'd, together with an optional raw fp16 copy for the 1x1 skip conv.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm statistics
+// grid = (nchunks, ninst); block 256 = 4 row-lanes x 64 column-lanes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_stats_partial_kernel(
+    const float* __restrict__ x1, int64_t ld1, int C1, const float* __restrict__ x2, int64_t ld2,
+    int C2, int64_t rows_per_inst, int rows_per_chunk, double* __restrict__ partial) {
+  __shared__ double acc[32][2];
+  const int t = threadIdx.x;
+  if (t < 64) acc[t >> 1][t & 1] = 0.0;
+  __syncthreads();
+  const int C = C1 + C2;
+  const int cg = C / 32;
+  const int cv4 = C >> 2;
+  const int inst = blockIdx.y, chunk = blockIdx.x;
+  const int64_t r0 = (int64_t)chunk * rows_per_chunk;
+  int64_t r1 = r0 + rows_per_chunk;
+  if (r1 > rows_per_inst) r1 = rows_per_inst;
+  const int64_t base = (int64_t)inst * rows_per_inst;
+  const int tx = t & 63, ty = t >> 6;
+  for (int cv = tx; cv < cv4; cv += 64) {
+    const int c = cv * 4;
+    const float* src;
+    int64_t ld;
+    if (c < C1) {
+      src = x1 + c;
+      ld = ld1;
+    } else {
+      src = x2 + (c - C1);
+      ld = ld2;
+    }
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    for (int64_t r = r0 + ty; r < r1; r += 4) {
+      const f32x4 v = *(const f32x4*)(src + (base + r) * ld);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double d = (double)v[e];
+        s[e] += d;
+        ss[e] += d * d;
+      }
+    }
+    // merge the (at most two) groups this float4 touches, then LDS atomics
+    const int g0 = c / cg, g3 = (c + 3) / cg;
+    if (g0 == g3) {
+      atomicAdd(&acc[g0][0], s[0] + s[1] + s[2] + s[3]);
+      atomicAdd(&acc[g0][1], ss[0] + ss[1] + ss[2] + ss[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int g = (c + e) / cg;
+        atomicAdd(&acc[g][0], s[e]);
+        atomicAdd(&acc[g][1], ss[e]);
+      }
+    }
+  }
+  __syncthreads();
+  if (t < 64) {
+    double* dst = partial + ((int64_t)inst * gridDim.x + chunk) * 64;
+    dst[t] = acc[t >> 1][t & 1];
+  }
+}
+
+// grid = ninst, block = 64: lane t -> (group t>>1, component t&1)
+__global__ __launch_bounds__(64) void gn_stats_final_kernel(const double* __restrict__ partial,
+                                                            int nchunks, double count, float eps,
+                                                            float* __restrict__ stats) {
+  const int inst = blockIdx.x, t = threadIdx.x;
+  double a = 0.0;
+  const double* src = partial + (int64_t)inst * nchunks * 64 + t;
+  for (int i = 0; i < nchunks; ++i) a += src[(int64_t)i * 64];
+  // lanes (2g, 2g+1) hold (sum, sumsq) of group g
+  const double other = __shfl_xor(a, 1);
+  const double sum = (t & 1) ? other : a;
+  const double sq = (t & 1) ? a : other;
+  const double mean = sum / count;
+  double var = sq / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float out = (t & 1) ? (float)(1.0 / sqrt(var + (double)eps)) : (float)mean;
+  stats[inst * 64 + t] = out;
+}
+
+extern "C" int gcd_groupnorm_stats(const float* x1, int64_t ld1, int C1, const float* x2,
+                                   int64_t ld2, int C2, int64_t M, int64_t rows_per_inst, float eps,
+                                   double* partial, int nchunks, float* stats, void* stream) {
+  const int C = C1 + C2;
+  GCD_CHECK_ARG(x1 && partial && stats, "gcd_groupnorm_stats: null pointer");
+  GCD_CHECK_ARG(C1 > 0 && C1 % 4 == 0 && C2 >= 0 && C2 % 4 == 0 && C % 32 == 0,
+                "gcd_groupnorm_stats: channels C1=%d C2=%d (need %%4 and C%%32)", C1, C2);
+  GCD_CHECK_ARG(C2 == 0 || x2, "gcd_groupnorm_stats: x2 null with C2=%d", C2);
+  GCD_CHECK_ARG(rows_per_inst > 0 && M > 0 && M % rows_per_inst == 0,
+                "gcd_groupnorm_stats: M=%lld not a multiple of rows_per_inst=%lld", (long long)M,
+                (long long)rows_per_inst);
+  GCD_CHECK_ARG(nchunks > 0 && nchunks <= 65535, "gcd_groupnorm_stats: nchunks=%d", nchunks);
+  GCD_CHECK_ARG(ld1 % 4 == 0 && (C2 == 0 || ld2 % 4 == 0), "gcd_groupnorm_stats: ld %% 4");
+  const int ninst = (int)(M / rows_per_inst);
+  const int rpc = (int)((rows_per_inst + nchunks - 1) / nchunks);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(nchunks, ninst), dim3(256), 0, s, x1, ld1, C1, x2,
+                     ld2, C2, rows_per_inst, rpc, partial);
+  GCD_CHECK_LAUNCH();
+  const double count = (double)rows_per_inst * (double)(C / 32);
+  hipLaunchKernelGGL(gn_stats_final_kernel, dim3(ninst), dim3(64), 0, s, partial, nchunks, count,
+                     eps, stats);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm apply (+SiLU) -> fp16, optional raw fp16 copy.
+// grid = (row chunks, ninst); block 256.  Per-channel scale/shift are built once per block in LDS.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_apply_kernel(
+    const float* __restrict__ x1, int64_t ld1, int C1, const float* __restrict__ x2, int64_t ld2,
+    int C2, int64_t rows_per_inst, int rows_per_chunk, const float* __restrict__ stats,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int silu, f16* __restrict__ y,
+    int64_t ldy, f16* __restrict__ raw, int64_t ldraw) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sc = (float*)smem_raw;  // [C] scale
+  const int C = C1 + C2;
+  float* sh = sc + C;            // [C] shift
+  const int cg = C / 32;
+  const int inst = blockIdx.y;
+  const int t = threadIdx.x;
+  for (int c = t; c < C; c += 256) {
+    const int g = c / cg;
+    const float mean = stats[inst * 64 + 2 * g], rstd = stats[inst * 64 + 2 * g + 1];
+    const float a = rstd * gamma[c];
+    sc[c] = a;
+    sh[c] = beta[c] - mean * a;
+  }
+  __syncthreads();
+  const int cv8 = C >> 3;  // 8-channel vectors per row
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk;
+  int64_t nrows = rows_per_inst - r0;
+  if (nrows > rows_per_chunk) nrows = rows_per_chunk;
+  const int64_t base = (int64_t)inst * rows_per_inst + r0;
+  const int64_t total = nrows * cv8;
+  for (int64_t idx = t; idx < total; idx += 256) {
+    const int64_t r = idx / cv8;
+    const int c = (int)(idx - r * cv8) * 8;
+    const float* src = (c < C1) ? x1 + (base + r) * ld1 + c : x2 + (base + r) * ld2 + (c - C1);
+    const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
+    const f32x4 a0 = *(const f32x4*)(sc + c), a1 = *(const f32x4*)(sc + c + 4);
+    const f32x4 b0 = *(const f32x4*)(sh + c), b1 = *(const f32x4*)(sh + c + 4);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float u0 = v0[e] * a0[e] + b0[e], u1 = v1[e] * a1[e] + b1[e];
+      if (silu) {
+        u0 = silu_f(u0);
+        u1 = silu_f(u1);
+      }
+      o[e] = (f16)u0;
+      o[e + 4] = (f16)u1;
+    }
+    *(f16x8*)(y + (base + r) * ldy + c) = o;
+    if (raw) {
+      f16x8 q;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        q[e] = (f16)v0[e];
+        q[e + 4] = (f16)v1[e];
+      }
+      *(f16x8*)(raw + (base + r) * ldraw + c) = q;
+    }
+  }
+}
+
+extern "C" int gcd_groupnorm_apply(const float* x1, int64_t ld1, int C1, const float* x2,
+                                   int64_t ld2, int C2, int64_t M, int64_t rows_per_inst,
+                                   const float* stats, const float* gamma, const float* beta,
+                                   int silu, void* y16, int64_t ldy, void* raw16, int64_t ldraw,
+                                   void* stream) {
+  const int C = C1 + C2;
+  GCD_CHECK_ARG(x1 && stats && gamma && beta && y16, "gcd_groupnorm_apply: null pointer");
+  GCD_CHECK_ARG(C1 > 0 && C1 % 8 == 0 && C2 >= 0 && C2 % 8 == 0 && C % 32 == 0,
+                "gcd_groupnorm_apply: channels C1=%d C2=%d (need %%8 and C%%32)", C1, C2);
+  GCD_CHECK_ARG(C2 == 0 || x2, "gcd_groupnorm_apply: x2 null with C2=%d", C2);
+  GCD_CHECK_ARG(rows_per_inst > 0 && M > 0 && M % rows_per_inst == 0,
+                "gcd_groupnorm_apply: M=%lld not a multiple of rows_per_inst=%lld", (long long)M,
+                (long long)rows_per_inst);
+  GCD_CHECK_ARG(ld1 % 4 == 0 && (C2 == 0 || ld2 % 4 == 0) && ldy % 8 == 0 &&
+                    (!raw16 || ldraw % 8 == 0),
+                "gcd_groupnorm_apply: leading dimensions must keep 16-byte alignment");
+  GCD_CHECK_ARG(C * 8 <= 64 * 1024, "gcd_groupnorm_apply: C=%d too large for the LDS table", C);
+  const int ninst = (int)(M / rows_per_inst);
+  // ~16 K elements per block keeps >= 1000 blocks in flight at the UNet's sizes
+  int rpc = (int)((16384 + C - 1) / C);
+  if (rpc < 1) rpc = 1;
+  int64_t nchunks = (rows_per_inst + rpc - 1) / rpc;
+  if (nchunks > 65535) {
+    nchunks = 65535;
+    rpc = (int)((rows_per_inst + nchunks - 1) / nchunks);
+    nchunks = (rows_per_inst + rpc - 1) / rpc;
+  }
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)nchunks, ninst), dim3(256), C * 8,
+                     (hipStream_t)stream, x1, ld1, C1, x2, ld2, C2, rows_per_inst, rpc, stats, gamma,
+                     beta, silu, (f16*)y16, ldy, (f16*)raw16, ldraw);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: one wavefront per token row, row held in registers (C <= 2048).
+// ------------------------------------------------------------------------------------------------
+template <int NV>  // float4 vectors per lane
+__global__ __launch_bounds__(256) void layernorm_kernel(
+    const float* __restrict__ x, int64_t ldx, int64_t M, int C, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, const float* __restrict__ addvec, int64_t ld_addvec,
+    int rows_per_vec, float* __restrict__ sum_out, int64_t ld_sum, f16* __restrict__ y,
+    int64_t ldy) {
+  const int lane = threadIdx.x & 63;
+  const int cv4 = C >> 2;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t m = wave0; m < M; m += nwaves) {
+    const float* row = x + m * ldx;
+    const float* av = addvec ? addvec + (m / rows_per_vec) * ld_addvec : nullptr;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int cv = lane + 64 * i;
+      if (cv < cv4) {
+        v[i] = *(const f32x4*)(row + cv * 4);
+        if (av) v[i] += *(const f32x4*)(av + cv * 4);
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+      } else {
+        v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int cv = lane + 64 * i;
+      if (cv < cv4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = v[i][e] - mean;
+          q += d * d;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int cv = lane + 64 * i;
+      if (cv < cv4) {
+        const f32x4 g = *(const f32x4*)(gamma + cv * 4), b = *(const f32x4*)(beta + cv * 4);
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (f16)((v[i][e] - mean) * rstd * g[e] + b[e]);
+        *(f16x4*)(y + m * ldy + cv * 4) = o;
+        if (sum_out) *(f32x4*)(sum_out + m * ld_sum + cv * 4) = v[i];
+      }
+    }
+  }
+}
+
+extern "C" int gcd_layernorm_f16(const float* x, int64_t ldx, int64_t M, int C, const float* gamma,
+                                 const float* beta, float eps, const float* addvec,
+                                 int64_t ld_addvec, int rows_per_vec, float* sum_out,
+                                 int64_t ld_sum, void* y16, int64_t ldy, void* stream) {
+  GCD_CHECK_ARG(x && gamma && beta && y16, "gcd_layernorm_f16: null pointer");
+  GCD_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 2048, "gcd_layernorm_f16: M=%lld C=%d",
+                (long long)M, C);
+  GCD_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0, "gcd_layernorm_f16: ld alignment");
+  if (addvec)
+    GCD_CHECK_ARG(rows_per_vec > 0 && ld_addvec % 4 == 0, "gcd_layernorm_f16: addvec geometry");
+  if (sum_out) GCD_CHECK_ARG(ld_sum % 4 == 0, "gcd_layernorm_f16: ld_sum alignment");
+  int64_t blocks = (M + 3) / 4;
+  if (blocks > 16384) blocks = 16384;  // grid-stride beyond 8 workgroups per CU
+  const int nv = (C / 4 + 63) / 64;
+  hipStream_t s = (hipStream_t)stream;
+#define GCD_LN_LAUNCH(NV)                                                                        \
+  hipLaunchKernelGGL(layernorm_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, M, C, \
+                     gamma, beta, eps, addvec, ld_addvec, rows_per_vec, sum_out, ld_sum,         \
+                     (f16*)y16, ldy)
+  switch (nv) {
+    case 1: GCD_LN_LAUNCH(1); break;
+    case 2: GCD_LN_LAUNCH(2); break;
+    case 3: GCD_LN_LAUNCH(3); break;
+    case 4: GCD_LN_LAUNCH(4); break;
+    case 5: GCD_LN_LAUNCH(5); break;
+    case 6: GCD_LN_LAUNCH(6); break;
+    case 7: GCD_LN_LAUNCH(7); break;
+    default: GCD_LN_LAUNCH(8); break;
+  }
+#undef GCD_LN_LAUNCH
+  GCD_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,228 @@
+"""Tensor-level wrappers over the libgcd_amd C ABI.
+
+torch is used here for device memory and the current HIP stream only; every function launches one
+hand-written gfx950 kernel through ctypes and raises if the tensors are not on a HIP device.
+Token-major convention: an activation of `frames x H x W x C` is a 2-D tensor [frames*H*W, C].
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (GEMM_CONV3X3, GEMM_PLAIN, GEMM_TEMPORAL3, OUT_F16, OUT_F32, OUT_GEGLU, GemmDesc,
+                   check)
+
+_zero_pages = {}
+
+
+def _need_gpu(*ts) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.GcdError(
+                "gcd_amd kernels run on an AMD GPU only (got a CPU tensor); there is no CPU fallback"
+            )
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def zero_page(device) -> torch.Tensor:
+    key = torch.device(device).index or 0
+    z = _zero_pages.get(key)
+    if z is None:
+        z = torch.zeros(1024, dtype=torch.float16, device=device)
+        _zero_pages[key] = z
+    return z
+
+
+def _ld(t: torch.Tensor) -> int:
+    assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D view"
+    return t.stride(0)
+
+
+def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mode: int = GEMM_PLAIN,
+         out_kind: int = OUT_F32, bias=None, rowvec=None, rows_per_vec: int = 1, r1=None, r2=None,
+         s_acc: float = 1.0, s_r1: float = 1.0, s_r2: float = 1.0, frame_alpha=None,
+         rows_per_alpha: int = 1, r1_blend: bool = False, conv=None) -> torch.Tensor:
+    """out = epilogue(A @ W^T); see gcd_gemm_desc in include/gcd_amd.h.
+
+    conv: dict(Cin, Hi, Wi, Ho, Wo, stride, upsample) for GEMM_CONV3X3 or dict(Cin, T, HW) for
+    GEMM_TEMPORAL3.  a16 is the token-major fp16 activation [rows, Cin].
+    """
+    _need_gpu(a16, w16, out)
+    assert a16.dtype == torch.float16 and w16.dtype == torch.float16
+    N, K = w16.shape
+    d = GemmDesc()
+    d.A, d.W, d.out = a16.data_ptr(), w16.data_ptr(), out.data_ptr()
+    d.lda, d.ldo = _ld(a16), _ld(out)
+    d.M, d.N, d.K, d.mode = M, N, K, mode
+    if mode != GEMM_PLAIN:
+        d.Cin = conv["Cin"]
+        d.Hi, d.Wi = conv.get("Hi", 0), conv.get("Wi", 0)
+        d.Ho, d.Wo = conv.get("Ho", 0), conv.get("Wo", 0)
+        d.stride, d.upsample = conv.get("stride", 1), int(conv.get("upsample", 0))
+        d.T, d.HW = conv.get("T", 0), conv.get("HW", 0)
+        d.zero_page = zero_page(a16.device).data_ptr()
+    d.bias = _p(bias)
+    if rowvec is not None:
+        d.rowvec, d.ld_rowvec, d.rows_per_vec = rowvec.data_ptr(), _ld(rowvec), rows_per_vec
+    if r1 is not None:
+        d.R1, d.ldr1 = r1.data_ptr(), _ld(r1)
+    if r2 is not None:
+        d.R2, d.ldr2 = r2.data_ptr(), _ld(r2)
+    d.s_acc, d.s_r1, d.s_r2 = s_acc, s_r1, s_r2
+    if frame_alpha is not None:
+        d.frame_alpha, d.rows_per_alpha, d.r1_blend = frame_alpha.data_ptr(), rows_per_alpha, int(r1_blend)
+    d.out_kind = out_kind
+    expect = torch.float32 if out_kind == OUT_F32 else torch.float16
+    assert out.dtype == expect, f"out dtype {out.dtype} does not match out_kind {out_kind}"
+    check(_lib.load().gcd_gemm_f16(C.byref(d), _stream()), "gcd_gemm_f16")
+    return out
+
+
+def linear_smallm(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], y: torch.Tensor, *,
+                  silu_in: bool = False, silu_out: bool = False, accumulate: bool = False):
+    _need_gpu(x, w, y)
+    assert x.dtype == w.dtype == y.dtype == torch.float32
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and w.is_contiguous() and y.shape == (M, N)
+    flags = int(silu_in) | (int(silu_out) << 1) | (int(accumulate) << 2)
+    check(_lib.load().gcd_linear_smallm_f32(x.data_ptr(), _ld(x), w.data_ptr(), _p(b), y.data_ptr(),
+                                            _ld(y), M, N, K, flags, _stream()),
+          "gcd_linear_smallm_f32")
+    return y
+
+
+def gn_nchunks(rows_per_inst: int) -> int:
+    return max(1, min(256, (rows_per_inst + 63) // 64))
+
+
+def groupnorm_stats(x1, x2, rows_per_inst: int, eps: float, partial: torch.Tensor,
+                    stats: torch.Tensor, nchunks: int):
+    _need_gpu(x1, x2, partial, stats)
+    M, C1 = x1.shape
+    C2 = 0 if x2 is None else x2.shape[1]
+    assert partial.dtype == torch.float64 and stats.dtype == torch.float32
+    ninst = M // rows_per_inst
+    assert partial.numel() >= ninst * nchunks * 64 and stats.numel() >= ninst * 64
+    check(_lib.load().gcd_groupnorm_stats(x1.data_ptr(), _ld(x1), C1, _p(x2),
+                                          0 if x2 is None else _ld(x2), C2, M, rows_per_inst,
+                                          eps, partial.data_ptr(), nchunks, stats.data_ptr(),
+                                          _stream()), "gcd_groupnorm_stats")
+    return stats
+
+
+def groupnorm_apply(x1, x2, rows_per_inst: int, stats, gamma, beta, silu: bool, y16, raw16=None):
+    _need_gpu(x1, x2, stats, gamma, beta, y16, raw16)
+    M, C1 = x1.shape
+    C2 = 0 if x2 is None else x2.shape[1]
+    check(_lib.load().gcd_groupnorm_apply(x1.data_ptr(), _ld(x1), C1, _p(x2),
+                                          0 if x2 is None else _ld(x2), C2, M, rows_per_inst,
+                                          stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                          int(silu), y16.data_ptr(), _ld(y16), _p(raw16),
+                                          0 if raw16 is None else _ld(raw16), _stream()),
+          "gcd_groupnorm_apply")
+    return y16
+
+
+def layernorm(x, gamma, beta, y16, *, eps: float = 1e-5, addvec=None, rows_per_vec: int = 1,
+              sum_out=None):
+    _need_gpu(x, gamma, beta, y16, addvec, sum_out)
+    M, Cc = x.shape
+    check(_lib.load().gcd_layernorm_f16(x.data_ptr(), _ld(x), M, Cc, gamma.data_ptr(),
+                                        beta.data_ptr(), eps, _p(addvec),
+                                        0 if addvec is None else _ld(addvec), rows_per_vec,
+                                        _p(sum_out), 0 if sum_out is None else _ld(sum_out),
+                                        y16.data_ptr(), _ld(y16), _stream()), "gcd_layernorm_f16")
+    return y16
+
+
+def attn_transpose_v(qkv16, frames: int, S: int, heads: int, vt16, S_pad: int):
+    _need_gpu(qkv16, vt16)
+    check(_lib.load().gcd_attn_transpose_v(qkv16.data_ptr(), _ld(qkv16), frames, S, heads,
+                                           vt16.data_ptr(), S_pad, _stream()),
+          "gcd_attn_transpose_v")
+    return vt16
+
+
+def attn_spatial(qkv16, vt16, S_pad: int, out16, frames: int, S: int, heads: int):
+    _need_gpu(qkv16, vt16, out16)
+    check(_lib.load().gcd_attn_spatial_f16(qkv16.data_ptr(), _ld(qkv16), vt16.data_ptr(), S_pad,
+                                           out16.data_ptr(), _ld(out16), frames, S, heads,
+                                           _stream()), "gcd_attn_spatial_f16")
+    return out16
+
+
+def attn_temporal(qkv16, out16, clips: int, T: int, HW: int, heads: int):
+    _need_gpu(qkv16, out16)
+    check(_lib.load().gcd_attn_temporal_f16(qkv16.data_ptr(), _ld(qkv16), out16.data_ptr(),
+                                            _ld(out16), clips, T, HW, heads, _stream()),
+          "gcd_attn_temporal_f16")
+    return out16
+
+
+def pack_input(x, concat, c_in, N: int, HW: int, out16, Cpad: int):
+    """x: [nx, Cx, H, W] fp32 contiguous; concat: [N, Cc, H, W] fp32 or None; out16: [N*HW, Cpad]."""
+    _need_gpu(x, concat, c_in, out16)
+    assert x.is_contiguous() and x.dtype == torch.float32
+    nx, Cx = x.shape[0], x.shape[1]
+    Cc = 0
+    if concat is not None:
+        assert concat.is_contiguous() and concat.dtype == torch.float32 and concat.shape[0] == N
+        Cc = concat.shape[1]
+    check(_lib.load().gcd_pack_input(x.data_ptr(), nx, Cx, _p(concat), Cc, _p(c_in), N, HW,
+                                     out16.data_ptr(), Cpad, _stream()), "gcd_pack_input")
+    return out16
+
+
+def unpack_output(tok32, out_nchw, Cout: int, N: int, HW: int):
+    _need_gpu(tok32, out_nchw)
+    assert out_nchw.is_contiguous() and out_nchw.dtype == torch.float32
+    check(_lib.load().gcd_unpack_output(tok32.data_ptr(), _ld(tok32), out_nchw.data_ptr(), Cout, N,
+                                        HW, _stream()), "gcd_unpack_output")
+    return out_nchw
+
+
+def cast_f16(x32, y16):
+    _need_gpu(x32, y16)
+    M, Cc = x32.shape
+    check(_lib.load().gcd_cast_f32_f16(x32.data_ptr(), _ld(x32), y16.data_ptr(), _ld(y16), M, Cc,
+                                       _stream()), "gcd_cast_f32_f16")
+    return y16
+
+
+def cfg_euler_step(x, net, scale, sig, x_out, T: int):
+    """x, x_out: [nx, C, H, W] fp32; net: [2*nx, C, H, W] fp32; sig: device [2] = (sigma, sigma_next)."""
+    _need_gpu(x, net, scale, sig, x_out)
+    assert x.is_contiguous() and net.is_contiguous() and x_out.is_contiguous()
+    nx = x.shape[0]
+    chw = x[0].numel()
+    assert net.shape[0] == 2 * nx and net[0].numel() == chw
+    check(_lib.load().gcd_cfg_euler_step(x.data_ptr(), net.data_ptr(), scale.data_ptr(),
+                                         sig.data_ptr(), x_out.data_ptr(), nx, T, chw, _stream()),
+          "gcd_cfg_euler_step")
+    return x_out
+
+
+def edm_scalings(sig, c_in, c_noise):
+    _need_gpu(sig, c_in, c_noise)
+    check(_lib.load().gcd_edm_scalings(sig.data_ptr(), c_in.data_ptr(), c_noise.data_ptr(),
+                                       c_in.numel(), _stream()), "gcd_edm_scalings")
+
+
+def timestep_embedding(t, emb, max_period: float = 10000.0):
+    _need_gpu(t, emb)
+    N, dim = emb.shape
+    assert emb.is_contiguous() and t.numel() == N and t.dtype == torch.float32
+    check(_lib.load().gcd_timestep_embedding(t.data_ptr(), emb.data_ptr(), N, dim, max_period,
+                                             _stream()), "gcd_timestep_embedding")
+    return emb

@@ -1,0 +1,190 @@
+/*
+ * gcd_amd.h — C ABI of libgcd_amd.so: the MI355X (gfx950 / CDNA4) kernels behind GCD's denoising
+ * hot path (SVD VideoUNet forward + EulerEDM sampling step).
+ *
+ * The reference (basilevh/gcd) has no FFI of its own: its hot path bottoms out in torch.nn ops
+ * (SURVEY.md §8b).  Every entry point below therefore cites the reference *operator* it replaces
+ * (path:line under /root/reference/gcd-model/), which is what a maintainer would bind with a
+ * ctypes stub from the sgm modules.
+ *
+ * Conventions
+ *   - Plain pointers + sizes only.  All pointers are DEVICE pointers unless stated otherwise.
+ *   - Activations are token-major ("NHWC"): a tensor of N frames x H x W pixels x C channels is a
+ *     row-major matrix [M = N*H*W, C] with an explicit leading dimension (in elements).
+ *   - The residual stream is fp32; MFMA operands (normalised activations, q/k/v, FF hidden) are
+ *     fp16; every contraction accumulates in fp32; norm statistics are fp32/fp64.
+ *   - Every launch goes to the caller's hipStream_t (passed as void*); nothing here synchronises,
+ *     allocates device memory or touches another stream, so a sequence of calls can be captured
+ *     into a hipGraph by the caller.
+ *   - Return value: 0 on success, non-zero on error; gcd_last_error() returns a thread-local
+ *     message for the last failing call.
+ */
+#ifndef GCD_AMD_H
+#define GCD_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCD_AMD_ABI_VERSION 1
+
+/* ---- library ------------------------------------------------------------------------------ */
+int gcd_abi_version(void);
+const char* gcd_last_error(void);
+/* Fills name (<= cap bytes) with the device's gcnArchName; fails if no HIP device is usable. */
+int gcd_device_info(int device, char* name, int cap, int* num_cus, size_t* hbm_bytes);
+
+/* ---- GEMM family (Linear / Conv2d 3x3 / Conv2d 1x1 / Conv3d (3,1,1) as implicit GEMM) ------ */
+/* A-operand addressing modes */
+#define GCD_GEMM_PLAIN 0     /* A is [M, K] fp16, row stride lda                          */
+#define GCD_GEMM_CONV3X3 1   /* A is NHWC fp16 [frames, Hi, Wi, Cin]; K = 9*Cin (kh,kw,cin) */
+#define GCD_GEMM_TEMPORAL3 2 /* A is [(b t) HW, Cin]; K = 3*Cin (kt,cin), zero pad in time  */
+
+/* epilogue output kinds */
+#define GCD_OUT_F32 0   /* out fp32 [M, N]                                    */
+#define GCD_OUT_F16 1   /* out fp16 [M, N]                                    */
+#define GCD_OUT_GEGLU 2 /* out fp16 [M, N/2] = a * gelu(g); weight rows interleaved per 16
+                           (rows 32j..32j+15 = value rows, 32j+16..32j+31 = gate rows)        */
+
+typedef struct gcd_gemm_desc {
+  /* operands */
+  const void* A;     /* fp16 */
+  const void* W;     /* fp16 [N, K] row-major (torch Linear layout; conv weights pre-permuted) */
+  void* out;         /* fp32 or fp16, see out_kind */
+  int64_t lda;       /* elements */
+  int64_t ldo;       /* elements */
+  int32_t M, N, K;
+  int32_t mode;      /* GCD_GEMM_* */
+  /* conv geometry (mode != PLAIN) */
+  int32_t Cin;       /* channels per tap */
+  int32_t Hi, Wi;    /* input spatial size (pre-upsample)        */
+  int32_t Ho, Wo;    /* output spatial size                       */
+  int32_t stride;    /* 1 or 2 (CONV3X3)                          */
+  int32_t upsample;  /* 1: nearest x2 upsample fused before conv  */
+  int32_t T;         /* frames per clip (TEMPORAL3)               */
+  int32_t HW;        /* pixels per frame (TEMPORAL3)              */
+  /* epilogue: out = s_acc[frame] * (acc + bias[n] + rowvec[m / rows_per_vec][n])
+                     + s_r1 * R1[m][n] + s_r2[frame] * R2[m][n]                               */
+  const float* bias;        /* [N] or NULL                                                    */
+  const float* rowvec;      /* [ceil(M/rows_per_vec), ld_rowvec] or NULL                      */
+  int64_t ld_rowvec;
+  int32_t rows_per_vec;
+  const float* R1;          /* fp32 residual or NULL (may alias out)                          */
+  int64_t ldr1;
+  const float* R2;          /* second fp32 residual (AlphaBlender partner) or NULL            */
+  int64_t ldr2;
+  float s_acc, s_r1, s_r2;  /* scalar scales used when frame_alpha == NULL                    */
+  const float* frame_alpha; /* optional [ceil(M/rows_per_alpha)]: if set, s_acc := (1-alpha),
+                               s_r2 := alpha (per frame), s_r1 := s_r1*(1-alpha) if r1_blend  */
+  int32_t rows_per_alpha;
+  int32_t r1_blend;
+  int32_t out_kind;         /* GCD_OUT_* */
+  const void* zero_page;    /* >= 256 B of zeros (device), required for conv modes            */
+} gcd_gemm_desc;
+
+/* Replaces torch.nn.Linear / Conv2d / Conv3d forward on the hot path:
+ *   attention.py:87-113 (GEGLU/FeedForward), attention.py:272-278,300-303,344 (q/k/v/out
+ *   projections), attention.py:663,693-699 (proj_in/proj_out), openaimodel.py:270-274,293-307,
+ *   311-318 (ResBlock convs, dims=2 and dims=3), openaimodel.py:139-142,199-206 (Up/Downsample),
+ *   diffusionmodules/util.py:358-369 (AlphaBlender, folded into the epilogue).                 */
+int gcd_gemm_f16(const gcd_gemm_desc* desc, void* stream);
+
+/* y[M,N] (fp32) = [y +] act_out( act_in(x[M,K]) @ W[N,K]^T + b ), fp32 weights, M <= 32.
+ * act flags: bit0 = SiLU on input, bit1 = SiLU on output, bit2 = accumulate into y.
+ * Replaces the tiny per-frame MLPs: video_model.py:155-200,485-497 (time/label/aux embeds),
+ * openaimodel.py:287-293 (emb_layers), video_attention.py:216-222 (time_pos_embed),
+ * and the 1-key cross-attention collapse to_out(to_v(ctx)) (attention.py:300-344).            */
+int gcd_linear_smallm_f32(const float* x, int64_t ldx, const float* W, const float* b, float* y,
+                          int64_t ldy, int M, int N, int K, int act_flags, void* stream);
+
+/* ---- normalisation -------------------------------------------------------------------------- */
+/* GroupNorm(32 groups) statistics over `rows_per_inst` consecutive rows (HW for a frame,
+ * T*HW for the time_stack variant) of x = [x1 (C1 ch) | x2 (C2 ch)] fp32.
+ * partial: workspace of ninst*nchunks*32*2 doubles; stats: ninst*32*2 floats (mean, rstd).
+ * Replaces diffusionmodules/util.py:259-276 (GroupNorm32) and attention.py:125-128 (Normalize). */
+int gcd_groupnorm_stats(const float* x1, int64_t ld1, int C1, const float* x2, int64_t ld2, int C2,
+                        int64_t M, int64_t rows_per_inst, float eps, double* partial, int nchunks,
+                        float* stats, void* stream);
+/* y16 = [silu]((x - mean) * rstd * gamma + beta) as fp16 [M, C1+C2]; raw16 (optional) = fp16(x). */
+int gcd_groupnorm_apply(const float* x1, int64_t ld1, int C1, const float* x2, int64_t ld2, int C2,
+                        int64_t M, int64_t rows_per_inst, const float* stats, const float* gamma,
+                        const float* beta, int silu, void* y16, int64_t ldy, void* raw16,
+                        int64_t ldraw, void* stream);
+/* LayerNorm over C of (x + addvec[m / rows_per_vec]) -> fp16; optionally writes the fp32 sum back
+ * (x_mix = x + time_pos_emb, video_attention.py:283-284).  Replaces nn.LayerNorm at
+ * attention.py:519-521 and video_attention.py:50,90-93.                                         */
+int gcd_layernorm_f16(const float* x, int64_t ldx, int64_t M, int C, const float* gamma,
+                      const float* beta, float eps, const float* addvec, int64_t ld_addvec,
+                      int rows_per_vec, float* sum_out, int64_t ld_sum, void* y16, int64_t ldy,
+                      void* stream);
+
+/* ---- attention ------------------------------------------------------------------------------ */
+/* vt[((f*heads+h)*64 + d) * S_pad + s] = qkv[(f*S+s)*ld + 2C + h*64 + d], zero padded to S_pad. */
+int gcd_attn_transpose_v(const void* qkv, int64_t ld, int frames, int S, int heads, void* vt,
+                         int S_pad, void* stream);
+/* Spatial self-attention, head dim 64, softmax scale 1/8 (F.scaled_dot_product_attention at
+ * attention.py:331-335).  qkv: fp16 [frames*S, 3C] (q | k | v, head-major columns), vt from
+ * gcd_attn_transpose_v, out: fp16 [frames*S, C].                                               */
+int gcd_attn_spatial_f16(const void* qkv, int64_t ld, const void* vt, int S_pad, void* out,
+                         int64_t ldo, int frames, int S, int heads, void* stream);
+/* Temporal self-attention over T <= 16 frames per (clip, pixel, head)
+ * (video_attention.py:114,126-129 -> attention.py:331-335).  Rows are ((b*T + t)*HW + s).       */
+int gcd_attn_temporal_f16(const void* qkv, int64_t ld, void* out, int64_t ldo, int clips, int T,
+                          int HW, int heads, void* stream);
+
+/* ---- UNet ends, casts ----------------------------------------------------------------------- */
+/* NCHW fp32 -> token-major fp16, fusing the sampler-side glue in front of the first conv:
+ *   out16[(n*HW + p)*Cpad + c] = x[n % nx][c][p] * c_in[n]      c < Cx       (denoiser.py:46-48,
+ *                              = concat[n][c - Cx][p]            c < Cx + Cc   guiders.py:89-100,
+ *                              = 0                               otherwise     wrappers.py:26)
+ * x: [nx, Cx, HW]; concat: [N, Cc, HW] or NULL; c_in: [N] or NULL (= 1); Cpad % 8 == 0.  The first
+ * conv (video_model.py:205-211, 8 -> 320 channels) then runs on the implicit-GEMM kernel with its
+ * input channels zero-padded to the 64-channel K granule.                                        */
+int gcd_pack_input(const float* x, int nx, int Cx, const float* concat, int Cc, const float* c_in,
+                   int N, int HW, void* out16, int Cpad, void* stream);
+/* token-major fp32 [N*HW, ld] (first Cout channels) -> NCHW fp32 [N, Cout, HW]: the layout change
+ * behind the final conv (video_model.py:455-459,537), whose 4 output channels are computed by the
+ * implicit-GEMM kernel with N padded to 16.                                                      */
+int gcd_unpack_output(const float* in, int64_t ld, float* out, int Cout, int N, int HW,
+                      void* stream);
+int gcd_cast_f32_f16(const float* x, int64_t ldx, void* y16, int64_t ldy, int64_t M, int C,
+                     void* stream);
+
+/* ---- sampler -------------------------------------------------------------------------------- */
+/* One fused EulerEDM update with LinearPredictionGuider CFG and the Denoiser affine:
+ *   D_u = net[n]*c_out + x*c_skip, D_c = net[n + nx]*c_out + x*c_skip      (denoiser.py:46-49)
+ *   D   = D_u + scale[n % T] * (D_c - D_u)                                  (guiders.py:79-87)
+ *   d   = (x - D) / sigma ; x_out = x + (sigma_next - sigma) * d            (sampling_utils.py:34-35,
+ *                                                                            sampling.py:86-87,114-117)
+ * x, x_out: [nx, chw] fp32 (may alias); net: [2*nx, chw] fp32; scale: [T] fp32 (device);
+ * sig: device pointer to {sigma, sigma_next} so that the same captured graph serves every step. */
+int gcd_cfg_euler_step(const float* x, const float* net, const float* scale, const float* sig,
+                       float* x_out, int nx, int T, int64_t chw, void* stream);
+/* c_in[n] = 1/sqrt(s^2+1), c_noise[n] = 0.25*ln(s) for every frame, from the device sigma
+ * (denoiser_scaling.py:53-61).                                                                 */
+int gcd_edm_scalings(const float* sig, float* c_in, float* c_noise, int N, void* stream);
+/* emb[n, :] = [cos(t_n f_k), sin(t_n f_k)], f_k = exp(-ln(max_period) k / half)
+ * (diffusionmodules/util.py:207-231).                                                          */
+int gcd_timestep_embedding(const float* t, float* emb, int N, int dim, float max_period,
+                           void* stream);
+
+/* ---- stream / graph plumbing ---------------------------------------------------------------- */
+int gcd_graph_begin_capture(void* stream);
+int gcd_graph_end_capture(void* stream, void** graph_exec_out);
+int gcd_graph_launch(void* graph_exec, void* stream);
+int gcd_graph_destroy(void* graph_exec);
+/* HIP events on an explicit stream (bench.py times kernels on the launch stream). */
+int gcd_event_create(void** ev);
+int gcd_event_record(void* ev, void* stream);
+int gcd_event_sync(void* ev);
+int gcd_event_elapsed_ms(void* start, void* stop, float* ms);
+int gcd_event_destroy(void* ev);
+int gcd_stream_sync(void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCD_AMD_H */
