@@ -1,0 +1,404 @@
+"""Per-kernel parity of libgcd_amd against plain PyTorch fp32 references (CPU).
+
+Operand precision is fp16 with fp32 accumulation, so inputs are rounded to fp16 *before* both
+paths; the remaining error is accumulation order + the fp16 rounding of fp16 outputs.
+Tolerances (rel-L2): fp32 outputs 2e-5 (norms) / 1e-4 (contractions), fp16 outputs 6e-4.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL_F32 = 1e-4
+TOL_F16 = 6e-4
+
+
+def _h(t):  # round to fp16 and back: the operand both paths see
+    return t.to(torch.float16).float()
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (128, 256, 64), (1000, 64, 640),
+                                   (257, 960, 128), (4032, 1280, 1280), (112, 48, 192)])
+def test_gemm_plain_bias_residual(gpu, M, N, K):
+    from gcd_amd import ops
+    g = _gen(1)
+    a = _h(torch.randn(M, K, generator=g))
+    w = _h(torch.randn(N, K, generator=g) / math.sqrt(K))
+    bias = torch.randn(N, generator=g)
+    rows_per_vec = 50
+    rv = torch.randn((M + rows_per_vec - 1) // rows_per_vec, N, generator=g)
+    r1 = torch.randn(M, N, generator=g)
+    r2 = torch.randn(M, N, generator=g)
+    ref = 0.7 * (a @ w.t() + bias + rv.repeat_interleave(rows_per_vec, 0)[:M]) + 0.5 * r1 - 1.25 * r2
+    out = torch.empty(M, N, device=gpu)
+    ops.gemm(a.half().to(gpu), w.half().to(gpu), out, M=M, bias=bias.to(gpu), rowvec=rv.to(gpu),
+             rows_per_vec=rows_per_vec, r1=r1.to(gpu), r2=r2.to(gpu), s_acc=0.7, s_r1=0.5, s_r2=-1.25)
+    torch.cuda.synchronize()
+    e = rel_l2(out, ref)
+    assert e < TOL_F32, f"gemm plain M={M} N={N} K={K}: rel-L2 {e:.3e}"
+    # fp16 output, no epilogue extras, transpose-detecting (asymmetric W)
+    out16 = torch.empty(M, N, device=gpu, dtype=torch.float16)
+    ops.gemm(a.half().to(gpu), w.half().to(gpu), out16, M=M, out_kind=ops.OUT_F16)
+    torch.cuda.synchronize()
+    e = rel_l2(out16.float(), a @ w.t())
+    assert e < TOL_F16, f"gemm f16 out M={M} N={N} K={K}: rel-L2 {e:.3e}"
+
+
+def test_gemm_inplace_residual_and_ld(gpu):
+    """R1 aliases out (residual stream update in place) and operands are strided views."""
+    from gcd_amd import ops
+    g = _gen(2)
+    M, N, K = 500, 320, 192
+    abuf = _h(torch.randn(M, K + 64, generator=g))
+    a = abuf[:, 8:8 + K]
+    w = _h(torch.randn(N, K, generator=g) / math.sqrt(K))
+    xbuf = torch.randn(M, N + 32, generator=g)
+    ref = xbuf[:, 4:4 + N] + a @ w.t()
+    xg = xbuf.to(gpu)
+    xv = xg[:, 4:4 + N]
+    ag = abuf.half().to(gpu)[:, 8:8 + K]
+    ops.gemm(ag, w.half().to(gpu), xv, M=M, r1=xv)
+    torch.cuda.synchronize()
+    assert rel_l2(xv, ref) < TOL_F32
+    # columns outside the view are untouched
+    assert torch.equal(xg[:, :4].cpu(), xbuf[:, :4]) and torch.equal(xg[:, 4 + N:].cpu(), xbuf[:, 4 + N:])
+
+
+def test_gemm_frame_alpha_blend(gpu):
+    from gcd_amd import ops
+    g = _gen(3)
+    rows_per_frame, frames, N, K = 48, 6, 160, 128
+    M = rows_per_frame * frames
+    a = _h(torch.randn(M, K, generator=g))
+    w = _h(torch.randn(N, K, generator=g) / math.sqrt(K))
+    bias = torch.randn(N, generator=g)
+    r1 = torch.randn(M, N, generator=g)
+    r2 = torch.randn(M, N, generator=g)
+    alpha = torch.tensor([0.3, 1.0, 0.62, 0.0, 1.0, 0.5])
+    al = alpha.repeat_interleave(rows_per_frame)[:, None]
+    # transformer form: alpha*x + (1-alpha)*(acc + bias + x3)
+    ref = al * r2 + (1 - al) * (a @ w.t() + bias + r1)
+    out = torch.empty(M, N, device=gpu)
+    ops.gemm(a.half().to(gpu), w.half().to(gpu), out, M=M, bias=bias.to(gpu), r1=r1.to(gpu),
+             r2=r2.to(gpu), frame_alpha=alpha.to(gpu), rows_per_alpha=rows_per_frame, r1_blend=True)
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < TOL_F32
+    # resblock form: x_s + (1-alpha)*(acc + bias)
+    ref = r1 + (1 - al) * (a @ w.t() + bias)
+    ops.gemm(a.half().to(gpu), w.half().to(gpu), out, M=M, bias=bias.to(gpu), r1=r1.to(gpu),
+             frame_alpha=alpha.to(gpu), rows_per_alpha=rows_per_frame, r1_blend=False)
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < TOL_F32
+
+
+@pytest.mark.parametrize("M,C", [(200, 64), (1024, 320), (130, 640)])
+def test_gemm_geglu(gpu, M, C):
+    from gcd_amd import ops, packing
+    g = _gen(4)
+    inner = 4 * C
+    a = _h(torch.randn(M, C, generator=g))
+    w = _h(torch.randn(2 * inner, C, generator=g) / math.sqrt(C))
+    b = torch.randn(2 * inner, generator=g)
+    h = a @ w.t() + b
+    ref = h[:, :inner] * F.gelu(h[:, inner:])
+    wp, bp = packing.pack_geglu(w, b)
+    out = torch.empty(M, inner, device=gpu, dtype=torch.float16)
+    ops.gemm(a.half().to(gpu), wp.to(gpu), out, M=M, bias=bp.to(gpu), out_kind=ops.OUT_GEGLU)
+    torch.cuda.synchronize()
+    e = rel_l2(out.float(), ref)
+    assert e < TOL_F16, f"geglu rel-L2 {e:.3e}"
+
+
+@pytest.mark.parametrize("frames,H,W,Cin,Cout,stride,up", [
+    (3, 10, 12, 64, 64, 1, 0), (2, 9, 7, 128, 320, 1, 0), (2, 12, 16, 64, 128, 2, 0),
+    (2, 9, 7, 64, 64, 2, 0), (2, 5, 6, 128, 64, 1, 1), (28, 16, 16, 64, 64, 1, 0)])
+def test_conv3x3(gpu, frames, H, W, Cin, Cout, stride, up):
+    from gcd_amd import ops, packing
+    g = _gen(5)
+    x = _h(torch.randn(frames, Cin, H, W, generator=g))
+    w = _h(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    b = torch.randn(Cout, generator=g)
+    emb = torch.randn(frames, Cout, generator=g)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    ref = F.conv2d(xin, w, b, stride=stride, padding=1) + emb[:, :, None, None]
+    Ho, Wo = ref.shape[-2:]
+    ref_tok = ref.permute(0, 2, 3, 1).reshape(frames * Ho * Wo, Cout)
+    a = x.permute(0, 2, 3, 1).reshape(frames * H * W, Cin).half().to(gpu)
+    out = torch.empty(frames * Ho * Wo, Cout, device=gpu)
+    ops.gemm(a, packing.pack_conv3x3(w).to(gpu), out, M=frames * Ho * Wo, mode=ops.GEMM_CONV3X3,
+             bias=b.to(gpu), rowvec=emb.to(gpu), rows_per_vec=Ho * Wo,
+             conv=dict(Cin=Cin, Hi=H, Wi=W, Ho=Ho, Wo=Wo, stride=stride, upsample=up))
+    torch.cuda.synchronize()
+    e = rel_l2(out, ref_tok)
+    assert e < TOL_F32, f"conv3x3 rel-L2 {e:.3e}"
+
+
+def test_conv3x3_padded_channels(gpu):
+    """First conv (8 -> C, input channels zero-padded to 64) and last conv (C -> 4, N padded to 16)."""
+    from gcd_amd import ops, packing
+    g = _gen(6)
+    frames, H, W = 2, 8, 8
+    x = _h(torch.randn(frames, 8, H, W, generator=g))
+    w = _h(torch.randn(64, 8, 3, 3, generator=g) / math.sqrt(72))
+    ref = F.conv2d(x, w, None, padding=1).permute(0, 2, 3, 1).reshape(-1, 64)
+    a = torch.zeros(frames * H * W, 64)
+    a[:, :8] = x.permute(0, 2, 3, 1).reshape(-1, 8)
+    out = torch.empty(frames * H * W, 64, device=gpu)
+    ops.gemm(a.half().to(gpu), packing.pack_conv3x3(w, cin_pad=64).to(gpu), out, M=frames * H * W,
+             mode=ops.GEMM_CONV3X3, conv=dict(Cin=64, Hi=H, Wi=W, Ho=H, Wo=W, stride=1, upsample=0))
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < TOL_F32
+    x2 = _h(torch.randn(frames, 64, H, W, generator=g))
+    w2 = _h(torch.randn(4, 64, 3, 3, generator=g) / math.sqrt(576))
+    b2 = torch.randn(4, generator=g)
+    ref2 = F.conv2d(x2, w2, b2, padding=1)
+    bp = torch.zeros(16)
+    bp[:4] = b2
+    out2 = torch.empty(frames * H * W, 16, device=gpu)
+    ops.gemm(x2.permute(0, 2, 3, 1).reshape(-1, 64).half().to(gpu),
+             packing.pack_conv3x3(w2, cout_pad=16).to(gpu), out2, M=frames * H * W,
+             mode=ops.GEMM_CONV3X3, bias=bp.to(gpu),
+             conv=dict(Cin=64, Hi=H, Wi=W, Ho=H, Wo=W, stride=1, upsample=0))
+    nchw = torch.empty(frames, 4, H, W, device=gpu)
+    ops.unpack_output(out2, nchw, 4, frames, H * W)
+    torch.cuda.synchronize()
+    assert rel_l2(nchw, ref2) < TOL_F32
+
+
+@pytest.mark.parametrize("clips,T,HW,C", [(2, 5, 12, 64), (2, 14, 64, 128), (1, 3, 200, 64)])
+def test_conv_temporal3(gpu, clips, T, HW, C):
+    from gcd_amd import ops, packing
+    g = _gen(7)
+    x = _h(torch.randn(clips, C, T, HW, 1, generator=g))          # b c t h w
+    w = _h(torch.randn(C, C, 3, 1, 1, generator=g) / math.sqrt(3 * C))
+    b = torch.randn(C, generator=g)
+    ref = F.conv3d(x, w, b, padding=(1, 0, 0))                     # b c t hw 1
+    ref_tok = ref[..., 0].permute(0, 2, 3, 1).reshape(clips * T * HW, C)
+    a = x[..., 0].permute(0, 2, 3, 1).reshape(clips * T * HW, C).half().to(gpu)
+    out = torch.empty(clips * T * HW, C, device=gpu)
+    ops.gemm(a, packing.pack_conv_t3(w).to(gpu), out, M=clips * T * HW, mode=ops.GEMM_TEMPORAL3,
+             bias=b.to(gpu), conv=dict(Cin=C, T=T, HW=HW))
+    torch.cuda.synchronize()
+    e = rel_l2(out, ref_tok)
+    assert e < TOL_F32, f"temporal conv rel-L2 {e:.3e}"
+
+
+# ----------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("frames,HW,C1,C2,per_clip_T", [
+    (4, 100, 320, 0, 0), (4, 37, 64, 0, 0), (3, 64, 640, 320, 0), (4, 50, 128, 0, 2),
+    (28, 256, 320, 0, 14), (2, 300, 1280, 640, 0)])
+def test_groupnorm(gpu, frames, HW, C1, C2, per_clip_T):
+    from gcd_amd import ops
+    g = _gen(8)
+    C = C1 + C2
+    x = torch.randn(frames, C, HW, generator=g) * 3 + 1.5          # n c hw, non-zero mean
+    gamma = torch.randn(C, generator=g)
+    beta = torch.randn(C, generator=g)
+    eps = 1e-5
+    if per_clip_T:  # time_stack GroupNorm: stats over (T, HW) per clip
+        xr = x.reshape(frames // per_clip_T, per_clip_T, C, HW).permute(0, 2, 1, 3)
+        ref = F.group_norm(xr, 32, gamma, beta, eps).permute(0, 2, 1, 3).reshape(frames, C, HW)
+        rows = per_clip_T * HW
+    else:
+        ref = F.group_norm(x, 32, gamma, beta, eps)
+        rows = HW
+    ref = F.silu(ref).permute(0, 2, 1).reshape(frames * HW, C)
+    tok = x.permute(0, 2, 1).reshape(frames * HW, C).contiguous()
+    x1 = tok[:, :C1].contiguous().to(gpu)
+    x2 = tok[:, C1:].contiguous().to(gpu) if C2 else None
+    nch = ops.gn_nchunks(rows)
+    ninst = frames * HW // rows
+    partial = torch.empty(ninst * nch * 64, dtype=torch.float64, device=gpu)
+    stats = torch.empty(ninst * 64, device=gpu)
+    ops.groupnorm_stats(x1, x2, rows, eps, partial, stats, nch)
+    y = torch.empty(frames * HW, C, dtype=torch.float16, device=gpu)
+    raw = torch.empty(frames * HW, C, dtype=torch.float16, device=gpu)
+    ops.groupnorm_apply(x1, x2, rows, stats, gamma.to(gpu), beta.to(gpu), True, y, raw)
+    torch.cuda.synchronize()
+    e = rel_l2(y.float(), ref)
+    assert e < TOL_F16, f"groupnorm rel-L2 {e:.3e}"
+    assert rel_l2(raw.float(), tok) < TOL_F16
+
+
+@pytest.mark.parametrize("M,C", [(100, 64), (1000, 320), (77, 640), (64, 1280)])
+def test_layernorm(gpu, M, C):
+    from gcd_amd import ops
+    g = _gen(9)
+    x = torch.randn(M, C, generator=g) * 2 + 0.5
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    rows_per_vec = 10
+    add = torch.randn((M + 9) // 10, C, generator=g)
+    xs = x + add.repeat_interleave(rows_per_vec, 0)[:M]
+    ref = F.layer_norm(xs, (C,), gamma, beta, 1e-5)
+    y = torch.empty(M, C, dtype=torch.float16, device=gpu)
+    s = torch.empty(M, C, device=gpu)
+    ops.layernorm(x.to(gpu), gamma.to(gpu), beta.to(gpu), y, addvec=add.to(gpu),
+                  rows_per_vec=rows_per_vec, sum_out=s)
+    torch.cuda.synchronize()
+    assert rel_l2(y.float(), ref) < TOL_F16
+    assert rel_l2(s, xs) < 1e-6
+    ops.layernorm(x.to(gpu), gamma.to(gpu), beta.to(gpu), y)
+    torch.cuda.synchronize()
+    assert rel_l2(y.float(), F.layer_norm(x, (C,), gamma, beta, 1e-5)) < TOL_F16
+
+
+# ------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("frames,S,heads", [(2, 4, 1), (2, 16, 2), (1, 64, 2), (2, 100, 3),
+                                            (2, 144, 2), (1, 200, 5), (2, 576, 2), (1, 1300, 1)])
+def test_attention_spatial(gpu, frames, S, heads):
+    from gcd_amd import ops
+    g = _gen(10)
+    C = heads * 64
+    qkv = _h(torch.randn(frames * S, 3 * C, generator=g) * 1.5)
+    # a spiked key forces a large running-max jump mid-sequence (online-softmax rescale path)
+    if S >= 100:
+        qkv[70, C:C + 64] *= 6.0
+    q, k, v = [t.reshape(frames, S, heads, 64).permute(0, 2, 1, 3) for t in qkv.split(C, dim=1)]
+    ref = F.scaled_dot_product_attention(q.double(), k.double(), v.double())
+    ref = ref.permute(0, 2, 1, 3).reshape(frames * S, C).float()
+    S_pad = (S + 63) // 64 * 64
+    qg = qkv.half().to(gpu)
+    vt = torch.empty(frames * heads * 64 * S_pad, dtype=torch.float16, device=gpu)
+    ops.attn_transpose_v(qg, frames, S, heads, vt, S_pad)
+    out = torch.empty(frames * S, C, dtype=torch.float16, device=gpu)
+    ops.attn_spatial(qg, vt, S_pad, out, frames, S, heads)
+    torch.cuda.synchronize()
+    vt_ref = torch.zeros(frames, heads, 64, S_pad)
+    vt_ref[..., :S] = v.permute(0, 1, 3, 2)
+    assert torch.equal(vt.cpu().float().reshape(frames, heads, 64, S_pad), vt_ref), "V^T mismatch"
+    e = rel_l2(out.float(), ref)
+    assert e < 1.5e-3, f"spatial attention S={S}: rel-L2 {e:.3e}"
+
+
+@pytest.mark.parametrize("clips,T,HW,heads", [(2, 14, 10, 3), (1, 4, 33, 1), (2, 16, 7, 5),
+                                              (2, 14, 64, 20)])
+def test_attention_temporal(gpu, clips, T, HW, heads):
+    from gcd_amd import ops
+    g = _gen(11)
+    C = heads * 64
+    M = clips * T * HW
+    qkv = _h(torch.randn(M, 3 * C, generator=g) * 1.5)
+    q, k, v = [t.reshape(clips, T, HW, heads, 64).permute(0, 2, 3, 1, 4) for t in qkv.split(C, dim=1)]
+    ref = F.scaled_dot_product_attention(q.double(), k.double(), v.double())   # b s h t d
+    ref = ref.permute(0, 3, 1, 2, 4).reshape(M, C).float()
+    out = torch.empty(M, C, dtype=torch.float16, device=gpu)
+    ops.attn_temporal(qkv.half().to(gpu), out, clips, T, HW, heads)
+    torch.cuda.synchronize()
+    e = rel_l2(out.float(), ref)
+    assert e < TOL_F16, f"temporal attention rel-L2 {e:.3e}"
+
+
+# ----------------------------------------------------------------------------------- small pieces
+@pytest.mark.parametrize("M,N,K", [(28, 1280, 320), (28, 1280, 1280), (14, 320, 1280), (2, 64, 1024),
+                                   (28, 100, 768), (28, 1280, 128)])
+def test_linear_smallm(gpu, M, N, K):
+    from gcd_amd import ops
+    g = _gen(12)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    y0 = torch.randn(M, N, generator=g)
+    ref = y0 + F.silu(F.linear(F.silu(x), w, b))
+    y = y0.clone().to(gpu)
+    ops.linear_smallm(x.to(gpu), w.to(gpu), b.to(gpu), y, silu_in=True, silu_out=True, accumulate=True)
+    torch.cuda.synchronize()
+    assert rel_l2(y, ref) < 1e-5
+    y = torch.empty(M, N, device=gpu)
+    ops.linear_smallm(x.to(gpu), w.to(gpu), None, y)
+    torch.cuda.synchronize()
+    assert rel_l2(y, F.linear(x, w)) < 1e-5
+
+
+def test_pack_unpack_cast(gpu):
+    from gcd_amd import ops
+    g = _gen(13)
+    nx, N, H, W = 3, 6, 5, 7
+    x = torch.randn(nx, 4, H, W, generator=g)
+    cc = torch.randn(N, 4, H, W, generator=g)
+    c_in = torch.rand(N, generator=g) + 0.5
+    ref = torch.zeros(N, H * W, 64)
+    ref[:, :, :4] = (x.repeat(2, 1, 1, 1) * c_in[:, None, None, None]).permute(0, 2, 3, 1).reshape(N, H * W, 4)
+    ref[:, :, 4:8] = cc.permute(0, 2, 3, 1).reshape(N, H * W, 4)
+    out = torch.full((N * H * W, 64), 7.0, dtype=torch.float16, device=gpu)
+    ops.pack_input(x.to(gpu), cc.to(gpu), c_in.to(gpu), N, H * W, out, 64)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref.reshape(-1, 64).half())
+    tok = torch.randn(N * H * W, 16, generator=g)
+    nchw = torch.empty(N, 4, H, W, device=gpu)
+    ops.unpack_output(tok.to(gpu), nchw, 4, N, H * W)
+    torch.cuda.synchronize()
+    assert torch.equal(nchw.cpu(), tok[:, :4].reshape(N, H, W, 4).permute(0, 3, 1, 2))
+    x32 = torch.randn(100, 64, generator=g)
+    y16 = torch.empty(100, 64, dtype=torch.float16, device=gpu)
+    ops.cast_f16(x32.to(gpu), y16)
+    torch.cuda.synchronize()
+    assert torch.equal(y16.cpu(), x32.half())
+
+
+def test_sampler_kernels(gpu):
+    from gcd_amd import ops
+    g = _gen(14)
+    nx, T = 4, 2
+    x = torch.randn(nx, 4, 6, 6, generator=g) * 50
+    net = torch.randn(2 * nx, 4, 6, 6, generator=g)
+    scale = torch.tensor([1.0, 1.5])
+    sigma, sigma_next = 37.5, 21.0
+    c_skip, c_out = 1 / (sigma ** 2 + 1), -sigma / math.sqrt(sigma ** 2 + 1)
+    den = net * c_out + torch.cat([x, x]) * c_skip
+    du, dc = den.chunk(2)
+    d_ = du + scale.repeat(nx // T)[:, None, None, None] * (dc - du)
+    ref = x + (sigma_next - sigma) * ((x - d_) / sigma)
+    out = torch.empty_like(x, device=gpu)
+    sig = torch.tensor([sigma, sigma_next], device=gpu)
+    ops.cfg_euler_step(x.to(gpu), net.to(gpu), scale.to(gpu), sig, out, T)
+    c_in, c_noise = torch.empty(8, device=gpu), torch.empty(8, device=gpu)
+    ops.edm_scalings(sig, c_in, c_noise)
+    t = torch.tensor([0.0, 1.6378, -1.55, 13.0], device=gpu)
+    emb = torch.empty(4, 320, device=gpu)
+    ops.timestep_embedding(t, emb)
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < 1e-5
+    assert abs(float(c_in[0]) - 1 / math.sqrt(sigma ** 2 + 1)) < 1e-7
+    assert abs(float(c_noise[3]) - 0.25 * math.log(sigma)) < 1e-6
+    half = 160
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+    args = t.cpu()[:, None] * freqs[None]
+    ref_emb = torch.cat([torch.cos(args), torch.sin(args)], -1)
+    assert (emb.cpu() - ref_emb).abs().max() < 2e-6
+
+
+def test_graph_capture_replay(gpu):
+    """A captured launch sequence replays with new data in the same buffers."""
+    import ctypes as C
+    from gcd_amd import _lib, ops
+    lib = _lib.load()
+    g = _gen(15)
+    M, N, K = 256, 160, 128
+    a = torch.randn(M, K, generator=g).half().to(gpu)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).half().to(gpu)
+    out = torch.zeros(M, N, device=gpu)
+    y16 = torch.zeros(M, N, dtype=torch.float16, device=gpu)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ops.gemm(a, w, out, M=M)          # warm up (module load, attribute set) outside capture
+        st.synchronize()
+        _lib.check(lib.gcd_graph_begin_capture(st.cuda_stream))
+        ops.gemm(a, w, out, M=M)
+        ops.cast_f16(out, y16)
+        exe = C.c_void_p()
+        _lib.check(lib.gcd_graph_end_capture(st.cuda_stream, C.byref(exe)))
+        a.copy_(torch.randn(M, K, generator=g).half())
+        st.synchronize()
+        _lib.check(lib.gcd_graph_launch(exe, st.cuda_stream))
+        _lib.check(lib.gcd_stream_sync(st.cuda_stream))
+    ref = a.float().cpu() @ w.float().cpu().t()
+    assert rel_l2(y16.float(), ref) < TOL_F16
+    _lib.check(lib.gcd_graph_destroy(exe))
