@@ -184,7 +184,7 @@ def test_conv_temporal3(gpu, clips, T, HW, C):
     b = torch.randn(C, generator=g)
     ref = F.conv3d(x, w, b, padding=(1, 0, 0))                     # b c t hw 1
     ref_tok = ref[..., 0].permute(0, 2, 3, 1).reshape(clips * T * HW, C)
-    a = x[..., 0].permute(0, 2, 3, 1).reshape(clips * T * HW, C).half().to(gpu)
+    a = x[..., 0].permute(0, 2, 3, 1).reshape(clips * T * HW, C).contiguous().half().to(gpu)
     out = torch.empty(clips * T * HW, C, device=gpu)
     ops.gemm(a, packing.pack_conv_t3(w).to(gpu), out, M=clips * T * HW, mode=ops.GEMM_TEMPORAL3,
              bias=b.to(gpu), conv=dict(Cin=C, T=T, HW=HW))
