@@ -1,0 +1,220 @@
+"""GPU: end-to-end parity of the HIP VideoUNet / sampler (through the C ABI) with the CPU oracle and
+the committed reference goldens.
+
+Tolerances (rel-L2 vs fp32 reference; operands are fp16 with fp32 accumulation and an fp32 residual
+stream — SURVEY.md §0.5 measured 1.8e-3 per forward / 8.4e-4 per loop for fp16 autocast):
+    single UNet forward      <= 2e-3
+    per-block activations    <= 2e-3
+    sampler trajectory/final <= 1e-3   (north_star: frames within 1e-3 rel-L2)
+"""
+from pathlib import Path
+
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import svd_unet_ref as O, weights
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+TOL_FWD = 2e-3
+TOL_LOOP = 1e-3
+
+
+def _build(cfg, gpu, salt=0):
+    from gcd_amd.video_model import VideoUNet
+    with torch.device("meta"):
+        net = VideoUNet(**cfg.as_reference_kwargs())
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = weights.synth_state_dict(shapes, salt)
+    net = net.to_empty(device=gpu)
+    net.load_state_dict(sd)
+    return net.eval(), sd
+
+
+def _unet_inputs(cfg, T, h, w, seed):
+    noise, c, uc = weights.synth_inputs(1, T, h, w, cfg.context_dim,
+                                        cfg.adm_in_channels + cfg.aux_emb_dim, seed)
+    x = torch.cat([torch.cat([noise, uc["concat"]], 1), torch.cat([noise, c["concat"]], 1)])
+    ts = torch.linspace(-1.5, 1.63, 2 * T)
+    return (x, ts, torch.cat([uc["crossattn"], c["crossattn"]]),
+            torch.cat([uc["vector"], c["vector"]]), torch.zeros(2, T))
+
+
+@pytest.fixture(scope="module")
+def tiny(gpu):
+    return _build(O.TINY, gpu)
+
+
+def test_unet_forward_vs_reference_golden(gpu, tiny):
+    """Same inputs / weights as the fixture made by the reference modules (oracle/make_golden.py)."""
+    net, sd = tiny
+    g = torch.load(GOLD / "unet_tiny.pt")
+    x, ts, ctx, y, ioi = _unet_inputs(O.TINY, g["T"], g["h"], g["w"], g["input_seed"])
+    net.engine.taps = {}
+    out = net(x.to(gpu), ts.to(gpu), context=ctx.to(gpu), y=y.to(gpu), num_video_frames=g["T"],
+              image_only_indicator=ioi.to(gpu))
+    torch.cuda.synchronize()
+    taps, net.engine.taps = net.engine.taps, None
+    errs = {}
+    for k, v in taps.items():
+        f = v.reshape(-1).cpu()
+        idx = torch.linspace(0, f.numel() - 1, min(4096, f.numel())).long()
+        errs[k] = rel_l2(f[idx], g["tap_samples"][k])
+    worst = max(errs, key=errs.get)
+    print("per-block rel-L2:", {k: f"{e:.2e}" for k, e in errs.items()})
+    assert set(taps) == set(g["tap_samples"])
+    assert errs[worst] < TOL_FWD, f"block {worst}: rel-L2 {errs[worst]:.3e}"
+    e = rel_l2(out, g["out"])
+    assert out.shape == g["out"].shape and out.dtype == torch.float32
+    assert e < TOL_FWD, f"UNet forward vs reference golden: rel-L2 {e:.3e}"
+
+
+@pytest.mark.parametrize("T,h,w,seed", [(14, 16, 16, 21), (2, 8, 24, 22), (1, 8, 8, 23), (16, 8, 8, 24)])
+def test_unet_forward_vs_oracle_shapes(gpu, tiny, T, h, w, seed):
+    """T = 14 (GCD), ragged aspect, single frame, maximum T of the temporal kernel."""
+    net, sd = tiny
+    x, ts, ctx, y, ioi = _unet_inputs(O.TINY, T, h, w, seed)
+    with torch.no_grad():
+        ref = O.unet_forward(sd, O.TINY, x, ts, ctx, y, T, ioi)
+    out = net(x.to(gpu), ts.to(gpu), context=ctx.to(gpu), y=y.to(gpu), num_video_frames=T,
+              image_only_indicator=ioi.to(gpu))
+    e = rel_l2(out, ref)
+    assert e < TOL_FWD, f"T={T} {h}x{w}: rel-L2 {e:.3e}"
+
+
+def test_unet_image_only_indicator_and_repeatability(gpu, tiny):
+    net, sd = tiny
+    T, h, w = 4, 8, 8
+    x, ts, ctx, y, ioi = _unet_inputs(O.TINY, T, h, w, 31)
+    ioi[0, 1] = 1.0
+    ioi[1, 3] = 1.0
+    with torch.no_grad():
+        ref = O.unet_forward(sd, O.TINY, x, ts, ctx, y, T, ioi)
+    args = (x.to(gpu), ts.to(gpu))
+    kw = dict(context=ctx.to(gpu), y=y.to(gpu), num_video_frames=T, image_only_indicator=ioi.to(gpu))
+    out1 = net(*args, **kw)
+    out2 = net(*args, **kw)
+    assert rel_l2(out1, ref) < TOL_FWD
+    assert torch.equal(out1, out2), "forward is not bit-reproducible run to run"
+
+
+def test_unet_rejects_bad_inputs(gpu, tiny):
+    net, _ = tiny
+    x, ts, ctx, y, ioi = _unet_inputs(O.TINY, 2, 8, 8, 41)
+    with pytest.raises(Exception):     # CPU tensors: no CPU path
+        net(x, ts, context=ctx, y=y, num_video_frames=2, image_only_indicator=ioi)
+    with pytest.raises(NotImplementedError):   # multi-token context is outside the SVD family
+        net(x.to(gpu), ts.to(gpu), context=ctx.repeat(1, 2, 1).to(gpu), y=y.to(gpu),
+            num_video_frames=2, image_only_indicator=ioi.to(gpu))
+    with pytest.raises(AssertionError):        # y width must be adm + aux (video_model.py:494)
+        net(x.to(gpu), ts.to(gpu), context=ctx.to(gpu), y=y[:, :-1].to(gpu), num_video_frames=2,
+            image_only_indicator=ioi.to(gpu))
+    with pytest.raises(ValueError):            # latent size must survive 3 downsamples
+        net(x[..., :6].to(gpu), ts.to(gpu), context=ctx.to(gpu), y=y.to(gpu), num_video_frames=2,
+            image_only_indicator=ioi.to(gpu))
+
+
+def test_state_dict_roundtrip_and_repack(gpu, tiny):
+    """load_state_dict with reference key names re-packs the fp16 operands."""
+    net, sd = tiny
+    x, ts, ctx, y, ioi = _unet_inputs(O.TINY, 2, 8, 8, 51)
+    kw = dict(context=ctx.to(gpu), y=y.to(gpu), num_video_frames=2, image_only_indicator=ioi.to(gpu))
+    out_a = net(x.to(gpu), ts.to(gpu), **kw)
+    g = torch.load(GOLD / "unet_tiny.pt")
+    sd2 = weights.synth_state_dict(g["state_dict_shapes"], salt=5)
+    net.load_state_dict(sd2)
+    with torch.no_grad():
+        ref = O.unet_forward(sd2, O.TINY, x, ts, ctx, y, 2, ioi)
+    out_b = net(x.to(gpu), ts.to(gpu), **kw)
+    assert rel_l2(out_b, ref) < TOL_FWD and rel_l2(out_b, out_a) > 0.1
+    net.load_state_dict(sd)            # restore for the other tests
+    assert set(net.state_dict().keys()) == set(g["state_dict_shapes"].keys())
+
+
+def _sampler(T, steps, device):
+    from gcd_amd.sampling import EulerEDMSampler
+    return EulerEDMSampler(
+        discretization_config={"target": "gcd_amd.discretizer.EDMDiscretization",
+                               "params": {"sigma_max": 700.0}},
+        num_steps=steps,
+        guider_config={"target": "gcd_amd.guiders.LinearPredictionGuider",
+                       "params": {"num_frames": T, "max_scale": 1.5, "min_scale": 1.0}},
+        device=device)
+
+
+def _stack(net, T, gpu):
+    from gcd_amd.denoiser import Denoiser
+    from gcd_amd.sampling import FusedDenoiser
+    from gcd_amd.wrappers import OpenAIWrapper
+    den = Denoiser({"target": "gcd_amd.denoiser_scaling.VScalingWithEDMcNoise"})
+    model = OpenAIWrapper(net)
+    extra = {"num_video_frames": T, "image_only_indicator": torch.zeros(2, T, device=gpu)}
+    return den, model, extra, FusedDenoiser(den, model, **extra)
+
+
+def test_sampler_vs_reference_golden(gpu, tiny):
+    """5 EulerEDM steps through the plugin stack: generic closure path, fused eager, fused graph."""
+    net, sd = tiny
+    g = torch.load(GOLD / "sampler_tiny.pt")
+    T, steps = g["T"], g["steps"]
+    noise, c, uc = weights.synth_inputs(1, T, g["h"], g["w"], O.TINY.context_dim,
+                                        O.TINY.adm_in_channels + O.TINY.aux_emb_dim, g["input_seed"])
+    cg = {k: v.to(gpu) for k, v in c.items()}
+    ucg = {k: v.to(gpu) for k, v in uc.items()}
+    den, model, extra, fused = _stack(net, T, gpu)
+    sampler = _sampler(T, steps, "cuda")
+
+    def closure(inp, sigma, cc):           # what DiffusionEngine.sample_video builds
+        return den(model, inp, sigma, cc, **extra)
+
+    out_generic = sampler(closure, noise.clone().to(gpu), cond=cg, uc=ucg)
+    assert sampler.last_path == "generic"
+    sampler.use_graph = False
+    out_fused = sampler(fused, noise.clone().to(gpu), cond=cg, uc=ucg)
+    assert sampler.last_path == "fused"
+    sampler.use_graph = True
+    out_graph = sampler(fused, noise.clone().to(gpu), cond=cg, uc=ucg)
+    torch.cuda.synchronize()
+    for name, o in [("generic", out_generic), ("fused", out_fused), ("graph", out_graph)]:
+        e = rel_l2(o, g["final"])
+        print(f"sampler {name}: rel-L2 vs reference golden {e:.3e}")
+        assert e < TOL_LOOP, f"{name}: {e:.3e}"
+    assert torch.equal(out_fused, out_graph), "hipGraph replay differs from eager launches"
+    assert rel_l2(out_fused, out_generic) < 2e-4
+
+
+def test_sampler_25_steps_T14_vs_oracle(gpu, tiny):
+    """The GCD configuration of the loop (25 steps, 14 frames, CFG 1.0 -> 1.5) at 16x16 latents."""
+    net, sd = tiny
+    T, steps, h, w = 14, 25, 16, 16
+    noise, c, uc = weights.synth_inputs(1, T, h, w, O.TINY.context_dim,
+                                        O.TINY.adm_in_channels + O.TINY.aux_emb_dim, 61)
+    trace = []
+    with torch.no_grad():
+        ref = O.sample_loop(sd, O.TINY, noise, c, uc, T, steps, trace=trace)
+    den, model, extra, fused = _stack(net, T, gpu)
+    sampler = _sampler(T, steps, "cuda")
+    out = sampler(fused, noise.clone().to(gpu), cond={k: v.to(gpu) for k, v in c.items()},
+                  uc={k: v.to(gpu) for k, v in uc.items()})
+    e = rel_l2(out, ref)
+    print(f"25-step loop rel-L2 {e:.3e}")
+    assert sampler.last_path == "fused" and e < TOL_LOOP, f"25-step loop: rel-L2 {e:.3e}"
+
+
+def test_unet_full_width_kubric_and_pardom(gpu):
+    """The real 1.5 B-parameter topology (320 base channels) at 14 x 16 x 16 latents, Kubric (camera
+    pose via aux_label_emb) and ParDom (no aux) variants, against the oracle on host cores."""
+    for cfg, salt in ((O.KUBRIC, 2), (O.PARDOM, 3)):
+        net, sd = _build(cfg, gpu, salt)
+        T, h, w = 14, 16, 16
+        x, ts, ctx, y, ioi = _unet_inputs(cfg, T, h, w, 71)
+        with torch.no_grad():
+            ref = O.unet_forward(sd, cfg, x, ts, ctx, y, T, ioi)
+        out = net(x.to(gpu), ts.to(gpu), context=ctx.to(gpu), y=y.to(gpu), num_video_frames=T,
+                  image_only_indicator=ioi.to(gpu))
+        e = rel_l2(out, ref)
+        print(f"full width aux={cfg.aux_emb_dim}: rel-L2 {e:.3e}, ws {net.engine.ws.nbytes() / 2**20:.0f} MiB")
+        assert e < TOL_FWD, f"full-width UNet (aux={cfg.aux_emb_dim}): rel-L2 {e:.3e}"
+        del net, sd
+        torch.cuda.empty_cache()
