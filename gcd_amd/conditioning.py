@@ -1,0 +1,101 @@
+"""Camera-pose / scalar conditioning embedders of GCD: drop-ins for
+sgm.modules.encoders.modules.{SphericalEmbedder, CameraEmbedder, ConcatTimestepEmbedderND}
+(reference encoders/modules.py:231-287, 1000-1016) with the same parameter names (`proj.weight`,
+`proj.bias`) so the GCD checkpoints' `conditioner.embedders.N.*` tensors load.
+
+They run once per clip and feed `c['vector']` (the 128-d pose embedding is what `aux_label_emb`
+injects into the UNet, video_model.py:491-497).  The projections run on libgcd_amd's fp32 small-M
+kernel and the sinusoids on gcd_timestep_embedding; like the rest of gcd_amd there is no CPU path.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _project(feats: torch.Tensor, proj: nn.Linear) -> torch.Tensor:
+    """feats [n, k] fp32 (cuda) -> proj(feats) via gcd_linear_smallm_f32 (K padded to 4, rows in
+    chunks of 32)."""
+    ops._need_gpu(feats, proj.weight)
+    n, k = feats.shape
+    kp = (k + 3) // 4 * 4
+    x = torch.zeros(n, kp, device=feats.device, dtype=torch.float32)
+    x[:, :k] = feats
+    w = torch.zeros(proj.out_features, kp, device=feats.device, dtype=torch.float32)
+    w[:, :k] = proj.weight.detach().float()
+    b = proj.bias.detach().float().contiguous()
+    out = torch.empty(n, proj.out_features, device=feats.device, dtype=torch.float32)
+    for r0 in range(0, n, 32):
+        ops.linear_smallm(x[r0:r0 + 32], w, b, out[r0:r0 + 32])
+    return out
+
+
+class AbstractEmbModel(nn.Module):
+    """Attribute surface GeneralConditioner expects (encoders/modules.py:25-81)."""
+
+    def __init__(self):
+        super().__init__()
+        self.is_trainable = False
+        self.ucg_rate = 0.0
+        self.input_key = None
+
+
+class SphericalEmbedder(AbstractEmbModel):
+    """(d_azimuth, d_elevation, d_radius) -> [cos, sin](az * {1,2,4}), [cos, sin](el * {1,2,4}), r
+    -> Linear(13, embed_dim)   (encoders/modules.py:247-287)."""
+
+    def __init__(self, embed_dim=128, zero_init=False):
+        super().__init__()
+        self.proj = nn.Linear(13, embed_dim)
+        if zero_init:
+            self.proj.weight.data.zero_()
+            self.proj.bias.data.zero_()
+
+    def forward(self, x):
+        assert x.shape[-1] == 3
+        lead = x.shape[:-1]
+        x = x.reshape(-1, 3).float()
+        cols = []
+        for ang in (x[:, 0], x[:, 1]):
+            for m in (1.0, 2.0, 4.0):
+                cols += [torch.cos(ang * m), torch.sin(ang * m)]
+        cols.append(x[:, 2])
+        return _project(torch.stack(cols, dim=-1), self.proj).reshape(*lead, -1)
+
+
+class CameraEmbedder(AbstractEmbModel):
+    """Flattened 3x4 extrinsics -> Linear(12, embed_dim)   (encoders/modules.py:231-244)."""
+
+    def __init__(self, embed_dim=128, zero_init=False):
+        super().__init__()
+        self.proj = nn.Linear(12, embed_dim)
+        if zero_init:
+            self.proj.weight.data.zero_()
+            self.proj.bias.data.zero_()
+
+    def forward(self, x):
+        assert x.shape[-2:] == (3, 4)
+        lead = x.shape[:-2]
+        return _project(x.reshape(-1, 12).float(), self.proj).reshape(*lead, -1)
+
+
+class ConcatTimestepEmbedderND(AbstractEmbModel):
+    """Sinusoid(outdim) of every scalar, concatenated (encoders/modules.py:1000-1016): fps_id,
+    motion_bucket_id, cond_aug -> 3 x 256 = the 768 `adm_in_channels`."""
+
+    def __init__(self, outdim):
+        super().__init__()
+        self.outdim = outdim
+
+    def forward(self, x):
+        if x.ndim == 1:
+            x = x[:, None]
+        assert len(x.shape) == 2
+        b, dims = x.shape
+        ops._need_gpu(x)
+        flat = x.reshape(-1).float().contiguous()
+        emb = torch.empty(b * dims, self.outdim, device=x.device, dtype=torch.float32)
+        ops.timestep_embedding(flat, emb, 10000.0)
+        return emb.reshape(b, dims * self.outdim)

@@ -545,7 +545,8 @@ class UNetEngine:
                 if k == "conv_in":
                     h = ws.alloc((M, L["cout"]), torch.float32)
                     ops.gemm(xin, L["w"], h, M=M, mode=GEMM_CONV3X3, bias=L["b"],
-                             conv=dict(Cin=CIN_PAD, Hi=H, Wi=W, Ho=H, Wo=W, stride=1, upsample=0))
+                             conv=dict(Cin=CIN_PAD, Hi=H, Wi=W, Ho=H, Wo=W, stride=1, upsample=0),
+                             alg_flops_scale=u.in_channels / CIN_PAD)
                     ws.release(xin)
                 elif k == "res":
                     hn = self._resblock(L, h, None, st)
@@ -590,7 +591,8 @@ class UNetEngine:
         ws.release(h)
         tok = ws.alloc((M, COUT_PAD), torch.float32)
         ops.gemm(a16, P["out_w"], tok, M=M, mode=GEMM_CONV3X3, bias=P["out_b"],
-                 conv=dict(Cin=u.model_channels, Hi=H, Wi=W, Ho=H, Wo=W, stride=1, upsample=0))
+                 conv=dict(Cin=u.model_channels, Hi=H, Wi=W, Ho=H, Wo=W, stride=1, upsample=0),
+                 alg_flops_scale=u.out_channels / COUT_PAD)
         ws.release(a16)
         ops.unpack_output(tok, out_nchw, u.out_channels, N, H * W)
         ws.release(tok)

@@ -17,6 +17,45 @@ from ._lib import (GEMM_CONV3X3, GEMM_PLAIN, GEMM_TEMPORAL3, OUT_F16, OUT_F32, O
 
 _zero_pages = {}
 
+# Optional per-launch profiler (bench.py): a list that receives one record per GEMM / attention
+# launch with HIP events recorded on the launch stream.  None = off (the default, zero overhead).
+_prof = None
+
+
+def start_profile() -> list:
+    global _prof
+    _prof = []
+    return _prof
+
+
+def stop_profile() -> None:
+    global _prof
+    _prof = None
+
+
+class _Timed:
+    """Brackets one kernel launch with HIP events on the current stream (profiling only)."""
+
+    def __init__(self, kind: str, flops: float, **info):
+        self.rec = None
+        if _prof is not None:
+            lib = _lib.load()
+            e0, e1 = C.c_void_p(), C.c_void_p()
+            check(lib.gcd_event_create(C.byref(e0)))
+            check(lib.gcd_event_create(C.byref(e1)))
+            self.rec = dict(kind=kind, flops=flops, start=e0, stop=e1, **info)
+
+    def __enter__(self):
+        if self.rec is not None:
+            check(_lib.load().gcd_event_record(self.rec["start"], _stream()))
+        return self
+
+    def __exit__(self, *exc):
+        if self.rec is not None:
+            check(_lib.load().gcd_event_record(self.rec["stop"], _stream()))
+            _prof.append(self.rec)
+        return False
+
 
 def _need_gpu(*ts) -> None:
     for t in ts:
@@ -51,7 +90,8 @@ def _ld(t: torch.Tensor) -> int:
 def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mode: int = GEMM_PLAIN,
          out_kind: int = OUT_F32, bias=None, rowvec=None, rows_per_vec: int = 1, r1=None, r2=None,
          s_acc: float = 1.0, s_r1: float = 1.0, s_r2: float = 1.0, frame_alpha=None,
-         rows_per_alpha: int = 1, r1_blend: bool = False, conv=None) -> torch.Tensor:
+         rows_per_alpha: int = 1, r1_blend: bool = False, conv=None,
+         alg_flops_scale: float = 1.0) -> torch.Tensor:
     """out = epilogue(A @ W^T); see gcd_gemm_desc in include/gcd_amd.h.
 
     conv: dict(Cin, Hi, Wi, Ho, Wo, stride, upsample) for GEMM_CONV3X3 or dict(Cin, T, HW) for
@@ -84,7 +124,8 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mod
     d.out_kind = out_kind
     expect = torch.float32 if out_kind == OUT_F32 else torch.float16
     assert out.dtype == expect, f"out dtype {out.dtype} does not match out_kind {out_kind}"
-    check(_lib.load().gcd_gemm_f16(C.byref(d), _stream()), "gcd_gemm_f16")
+    with _Timed("gemm", 2.0 * M * N * K * alg_flops_scale, M=M, N=N, K=K, mode=mode):
+        check(_lib.load().gcd_gemm_f16(C.byref(d), _stream()), "gcd_gemm_f16")
     return out
 
 
@@ -156,9 +197,10 @@ def attn_transpose_v(qkv16, frames: int, S: int, heads: int, vt16, S_pad: int):
 
 def attn_spatial(qkv16, vt16, S_pad: int, out16, frames: int, S: int, heads: int):
     _need_gpu(qkv16, vt16, out16)
-    check(_lib.load().gcd_attn_spatial_f16(qkv16.data_ptr(), _ld(qkv16), vt16.data_ptr(), S_pad,
-                                           out16.data_ptr(), _ld(out16), frames, S, heads,
-                                           _stream()), "gcd_attn_spatial_f16")
+    with _Timed("attn_spatial", 4.0 * frames * heads * S * S * 64, S=S, frames=frames, heads=heads):
+        check(_lib.load().gcd_attn_spatial_f16(qkv16.data_ptr(), _ld(qkv16), vt16.data_ptr(), S_pad,
+                                               out16.data_ptr(), _ld(out16), frames, S, heads,
+                                               _stream()), "gcd_attn_spatial_f16")
     return out16
 
 

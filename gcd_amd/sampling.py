@@ -131,62 +131,103 @@ class EDMSampler(BaseDiffusionSampler):
         return x.shape[1] + cond["concat"].shape[1] == unet.in_channels
 
     def _call_fused(self, fd: FusedDenoiser, x, cond, uc, num_steps):
+        loop = FusedEulerLoop(self, fd, x, cond, uc, num_steps)
+        try:
+            with loop:
+                for i in range(loop.num_steps):
+                    loop.step(i)
+        finally:
+            loop.close()
+        return loop.x
+
+
+class FusedEulerLoop:
+    """Device-resident EulerEDM loop: static buffers + one hipGraph replay per step.
+
+    Step i computes, entirely in libgcd_amd kernels on a side stream:
+        c_in, c_noise   <- sigma_i                         (gcd_edm_scalings)
+        net             <- VideoUNet([x*c_in | concat] for [uc | c])   (engine.run, CFG batch 2*nx)
+        x               <- Euler(CFG(denoiser affine(net)))            (gcd_cfg_euler_step)
+    The first step runs eagerly (it also records the workspace placement), the second is captured
+    into a hipGraph, later steps replay it; sigma is read from a 2-float device buffer refreshed by
+    a device-to-device copy from the sigma table before each replay.
+    """
+
+    def __init__(self, sampler: "EDMSampler", fd: FusedDenoiser, x, cond, uc, num_steps=None):
         unet: VideoUNet = fd.network.diffusion_model
-        eng = unet.engine
+        self.eng = eng = unet.engine
         if eng.packed is None:
             eng.pack()
-        T = fd.additional_model_inputs["num_video_frames"]
+        self.T = T = fd.additional_model_inputs["num_video_frames"]
         ioi = fd.additional_model_inputs.get("image_only_indicator")
-        dev = x.device
-        sigmas = self.discretization(self.num_steps if num_steps is None else num_steps,
-                                     device=self.device).to(device=dev, dtype=torch.float32)
-        x *= torch.sqrt(1.0 + sigmas[0] ** 2.0)          # caller's tensor, like sampling.py:54
+        self.dev = dev = x.device
+        self.sigmas = sampler.discretization(
+            sampler.num_steps if num_steps is None else num_steps,
+            device=sampler.device).to(device=dev, dtype=torch.float32)
+        self.num_steps = len(self.sigmas) - 1
+        x *= torch.sqrt(1.0 + self.sigmas[0] ** 2.0)     # caller's tensor, like sampling.py:54
         nx = x.shape[0]
         N = 2 * nx
-        # ---- static buffers (guiders.py:89-100: batch = [uc | c]) ----
         f32 = dict(device=dev, dtype=torch.float32)
-        xs = x.detach().clone().contiguous()
-        concat2 = torch.cat((uc["concat"], cond["concat"]), 0).to(**f32).contiguous()
-        ctx2 = torch.cat((uc["crossattn"], cond["crossattn"]), 0).to(**f32).contiguous()
-        y2 = torch.cat((uc["vector"], cond["vector"]), 0).to(**f32).contiguous()
-        net_out = torch.empty(N, unet.out_channels, *x.shape[2:], **f32)
-        c_in, c_noise = torch.empty(N, **f32), torch.empty(N, **f32)
-        sig = torch.empty(2, **f32)
-        scale = self.guider.scale.reshape(-1).to(**f32).contiguous()
-        alphas = eng.blend_alphas(ioi, N, T)
-        lib = _lib.load()
+        # static buffers; batch order [uc | c] as in guiders.py:89-100
+        self.x = x.detach().clone().contiguous()
+        self.concat2 = torch.cat((uc["concat"], cond["concat"]), 0).to(**f32).contiguous()
+        self.ctx2 = torch.cat((uc["crossattn"], cond["crossattn"]), 0).to(**f32).contiguous()
+        self.y2 = torch.cat((uc["vector"], cond["vector"]), 0).to(**f32).contiguous()
+        self.net_out = torch.empty(N, unet.out_channels, *x.shape[2:], **f32)
+        self.c_in, self.c_noise = torch.empty(N, **f32), torch.empty(N, **f32)
+        self.sig = torch.empty(2, **f32)
+        self.scale = sampler.guider.scale.reshape(-1).to(**f32).contiguous()
+        self.alphas = eng.blend_alphas(ioi, N, T)
+        self.use_graph = sampler.use_graph
+        self.lib = _lib.load()
+        self.graph = C.c_void_p()
+        self.side = torch.cuda.Stream(device=dev)
+        self._ctx = None
+        self._eager_done = 0
 
-        def step():
-            ops.edm_scalings(sig, c_in, c_noise)
-            eng.run(xs, concat2, c_in, c_noise, ctx2, y2, T, None, net_out, alphas=alphas)
-            ops.cfg_euler_step(xs, net_out, scale, sig, xs, T)
+    # the side stream is current inside `with loop:` so that every launch lands on it
+    def __enter__(self):
+        self.side.wait_stream(torch.cuda.current_stream(self.dev))
+        self._ctx = torch.cuda.stream(self.side)
+        self._ctx.__enter__()
+        return self
 
-        n = len(sigmas) - 1
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        graph = C.c_void_p()
-        try:
-            with torch.cuda.stream(side):
-                for i in range(n):
-                    sig.copy_(sigmas[i:i + 2])
-                    if not self.use_graph or i == 0 or n < 3:
-                        step()                                   # eager (also warms the workspace)
-                    elif i == 1:
-                        _lib.check(lib.gcd_graph_begin_capture(side.cuda_stream), "graph capture")
-                        try:
-                            step()
-                        finally:
-                            _lib.check(lib.gcd_graph_end_capture(side.cuda_stream, C.byref(graph)),
-                                       "graph instantiate")
-                        _lib.check(lib.gcd_graph_launch(graph, side.cuda_stream), "graph launch")
-                    else:
-                        _lib.check(lib.gcd_graph_launch(graph, side.cuda_stream), "graph launch")
-                side.synchronize()
-        finally:
-            if graph:
-                lib.gcd_graph_destroy(graph)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        return xs
+    def __exit__(self, *exc):
+        self.side.synchronize()
+        self._ctx.__exit__(*exc)
+        self._ctx = None
+        torch.cuda.current_stream(self.dev).wait_stream(self.side)
+        return False
+
+    def launch_step(self):
+        ops.edm_scalings(self.sig, self.c_in, self.c_noise)
+        self.eng.run(self.x, self.concat2, self.c_in, self.c_noise, self.ctx2, self.y2, self.T, None,
+                     self.net_out, alphas=self.alphas)
+        ops.cfg_euler_step(self.x, self.net_out, self.scale, self.sig, self.x, self.T)
+
+    def step(self, i: int):
+        """Run step i (sigma_i -> sigma_{i+1}); indices beyond the schedule wrap (benchmarking)."""
+        k = i % self.num_steps
+        self.sig.copy_(self.sigmas[k:k + 2])
+        if not self.use_graph or self._eager_done < 1:
+            self.launch_step()
+            self._eager_done += 1
+        elif not self.graph:
+            _lib.check(self.lib.gcd_graph_begin_capture(self.side.cuda_stream), "graph capture")
+            try:
+                self.launch_step()
+            finally:
+                _lib.check(self.lib.gcd_graph_end_capture(self.side.cuda_stream, C.byref(self.graph)),
+                           "graph instantiate")
+            _lib.check(self.lib.gcd_graph_launch(self.graph, self.side.cuda_stream), "graph launch")
+        else:
+            _lib.check(self.lib.gcd_graph_launch(self.graph, self.side.cuda_stream), "graph launch")
+
+    def close(self):
+        if self.graph:
+            self.lib.gcd_graph_destroy(self.graph)
+            self.graph = C.c_void_p()
 
 
 class EulerEDMSampler(EDMSampler):
