@@ -46,6 +46,7 @@ SIGNATURES = {
     "gcd_abi_version": (_i, []),
     "gcd_last_error": (C.c_char_p, []),
     "gcd_device_info": (_i, [_i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(C.c_size_t)]),
+    "gcd_tune_set": (_i, [_i, _i]),
     "gcd_gemm_f16": (_i, [C.POINTER(GemmDesc), _vp]),
     "gcd_linear_smallm_f32": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "gcd_groupnorm_stats": (_i, [_vp, _i64, _i, _vp, _i64, _i, _i64, _i64, _f, _vp, _i, _vp, _vp]),

@@ -23,31 +23,8 @@
 //     sweep N fastest, so an A row-panel is fetched from HBM once and re-read from that XCD's L2.
 //   * Epilogue fuses bias, per-frame vectors (timestep embedding / collapsed 1-key cross-attention),
 //     up to two fp32 residual streams with AlphaBlender scaling, GEGLU, and the fp16 down-cast.
-#include "common.h"
+#include "gemm_common.h"
 
-struct GemmK {
-  const f16* A;
-  const f16* W;
-  void* out;
-  int64_t lda, ldo;
-  int M, N, K;
-  int Cin, Hi, Wi, Ho, Wo, stride, up, T, HW;
-  const float* bias;
-  const float* rowvec;
-  int64_t ld_rowvec;
-  int rows_per_vec;
-  const float* R1;
-  int64_t ldr1;
-  const float* R2;
-  int64_t ldr2;
-  float s_acc, s_r1, s_r2;
-  const float* frame_alpha;
-  int rows_per_alpha;
-  int r1_blend;
-  int out_kind;
-  const f16* zero;
-  int tiles_m, tiles_n;
-};
 
 template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmK p) {
@@ -350,8 +327,18 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
   k.tiles_m = k.tiles_n = 0;
   hipStream_t s = (hipStream_t)stream;
 
+  // kernel choice: the 256 x 320 ping-pong kernel whenever the grid fills most of the chip with
+  // its (large) tiles, the general 128-row kernel otherwise.  GCD_TUNE_GEMM_IMPL overrides.
+  const int impl = gcd_tune_get(GCD_TUNE_GEMM_IMPL);
+  bool use_pp = false;
+  if (impl != 1 && gcd_gemm_pp_supported(k, d->mode)) {
+    const int64_t tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 319) / 320);
+    use_pp = impl >= 2 || (tiles >= 192 && d->N >= 160);
+  }
+
   switch (d->mode) {
     case GCD_GEMM_PLAIN:
+      if (use_pp) return gcd_gemm_pp_launch(k, d->mode, s);
       return dispatch_tile<GCD_GEMM_PLAIN>(k, s);
     case GCD_GEMM_CONV3X3: {
       GCD_CHECK_ARG(d->zero_page, "gcd_gemm_f16: conv mode needs a zero page");
@@ -368,6 +355,7 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
         GCD_CHECK_ARG(d->Ho == (d->Hi - 1) / d->stride + 1 && d->Wo == (d->Wi - 1) / d->stride + 1,
                       "gcd_gemm_f16: conv3x3 pad-1 geometry mismatch (%dx%d -> %dx%d, stride %d)",
                       d->Hi, d->Wi, d->Ho, d->Wo, d->stride);
+      if (use_pp) return gcd_gemm_pp_launch(k, d->mode, s);
       return dispatch_tile<GCD_GEMM_CONV3X3>(k, s);
     }
     case GCD_GEMM_TEMPORAL3: {
@@ -376,6 +364,7 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
                     "gcd_gemm_f16: temporal3 needs Cin %% 64 == 0 and K == 3*Cin");
       GCD_CHECK_ARG(d->T > 0 && d->HW > 0 && d->M % (d->T * d->HW) == 0,
                     "gcd_gemm_f16: M=%d is not clips*T*HW (T=%d HW=%d)", d->M, d->T, d->HW);
+      if (use_pp) return gcd_gemm_pp_launch(k, d->mode, s);
       return dispatch_tile<GCD_GEMM_TEMPORAL3>(k, s);
     }
     default:

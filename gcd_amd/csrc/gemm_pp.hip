@@ -1,0 +1,422 @@
+// gemm_pp.hip — 256 x 320 "ping-pong" MFMA GEMM for gfx950 (MI355X): the fast path of the GEMM
+// family (nn.Linear, Conv2d 3x3 / 1x1, Conv3d (3,1,1) as implicit GEMMs) on the large-M shapes of
+// the SVD VideoUNet.  Same contract and epilogue as gemm.hip (see gcd_gemm_desc); gemm.hip remains
+// the general kernel for small / ragged problems.
+//
+// Why this shape.  Every output width of the UNet is a multiple of 320 (320, 640, 960, 1280, 1920,
+// 2560, 3840, 5120, 10240) and every token count but the bottleneck's is a multiple of 256, so a
+// 256 x 320 block tile has no padding waste.  Per 32-deep K slice a CU stages (256 + 320) x 64 B =
+// 36 KB for 2*256*320*32 = 5.2 MFLOP, i.e. 28.8 B per MFMA clock — well inside the 64 B/clk of the
+// vector-memory -> LDS path that caps 128 x 128 tiles at ~900 TFLOP/s.
+//
+// Structure (one workgroup = 8 waves = 2 per SIMD, one workgroup per CU):
+//   * waves form a 4 (M) x 2 (N) grid; a wave owns 64 tokens x 160 channels = 2 x 5 tiles of
+//     v_mfma_f32_32x32x16_f16 (operands swapped: W rows are the MFMA "A" operand, so a lane ends up
+//     with 4 consecutive output channels of one token and the epilogue moves 16-byte vectors);
+//   * K is consumed in 32-deep sub-tiles that live in a ring of FOUR 36 KB LDS slots (144 of the
+//     160 KB); global_load_lds_dwordx4 (LDS-DMA) fills a slot three sub-tiles ahead of its use.
+//     The LDS image of a DMA is lane-linear, so the bank swizzle (chunk ^= (row >> 2) & 3) is
+//     applied to the per-lane SOURCE address and undone by the ds_read_b128 address;
+//   * the two wave groups (waves 0-3 / 4-7, one of each per SIMD) run the same phase sequence
+//         { ds_read 7 fragments + issue <= 3 DMA pieces | s_barrier | 10 MFMA | s_barrier }
+//     but group 1 is shifted by ONE barrier: while one wave of a SIMD feeds the matrix pipe its
+//     partner reads LDS and issues DMA, then they swap (2 phases per sub-tile, 16-deep each);
+//   * DMA completion is tracked with COUNTED s_waitcnt vmcnt(8) (never 0 in steady state): a wave
+//     only waits for the pieces of the sub-tile that is read two barriers later; 8 newer pieces
+//     stay in flight across the barriers.
+//   * hazards (sigma = sub-tile index, slot = sigma & 3):
+//       RAW  a reader passes a barrier that every wave reached after its own counted wait for sigma;
+//       WAR  a slot is re-filled at the earliest two barriers after the last ds_read of its previous
+//            content was retired by the reading wave's lgkmcnt wait.
+//   * blockIdx -> tile map: each XCD owns a contiguous range of tiles, walked in groups of 4 M-tiles
+//     x all N-tiles with M fastest, so the 32 workgroups an XCD runs concurrently share A row panels
+//     and W column panels through that XCD's L2.
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int PP_BM = 256, PP_BN = 320;
+constexpr int PP_A_BYTES = PP_BM * 64;                  // A sub-tile: 256 rows x 32 fp16
+constexpr int PP_W_BYTES = PP_BN * 64;                  // W sub-tile: 320 rows x 32 fp16
+constexpr int PP_SLOT = PP_A_BYTES + PP_W_BYTES;        // 36864
+constexpr int PP_SMEM = 4 * PP_SLOT;                    // 147456
+constexpr int PP_GROUP_M = 4;
+
+#define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+// VAR: ablation switches for tools/gemm_bench (0 = the product kernel; any other value computes
+// WRONG results and exists only to price the parts of the loop):
+//   1 no DMA in the main loop   2 no ds_read in the loop   4 no one-barrier stagger
+//   8 no s_setprio             16 no barriers in the loop
+template <int MODE, int VAR>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = wave >> 2;            // 0 leads, 1 runs one barrier behind
+  const int wm = wave & 3, wn = grp;
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  // ---- XCD-aware, panel-sharing tile assignment (bijective for any grid) ----
+  int tile_m, tile_n;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int per_group = PP_GROUP_M * p.tiles_n;
+    const int gi = L / per_group;
+    const int rem = L - gi * per_group;
+    const int m_first = gi * PP_GROUP_M;
+    const int gm = min(PP_GROUP_M, p.tiles_m - m_first);
+    tile_n = rem / gm;
+    tile_m = m_first + rem - tile_n * gm;
+  }
+  const int m0 = tile_m * PP_BM, n0 = tile_n * PP_BN;
+  const int S = p.K >> 5;               // number of 32-deep sub-tiles
+
+  // ---- DMA bookkeeping: a piece = 16 rows x 64 B = one global_load_lds_dwordx4 of a wave ----
+  const int lrow = lane >> 2;
+  const int lc16 = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;   // logical 16-B chunk this lane fetches
+  // A: wave w loads pieces 2w, 2w+1 (tile rows 32w .. 32w+31)
+  const char* a_base[2];
+  int a_inc[2];              // bytes per channel step: 2, or 0 when the tap reads the zero page
+  int a_y[2], a_x[2];
+  int64_t a_fb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int m = m0 + 32 * wave + 16 * i + lrow;
+    m = m < p.M ? m : p.M - 1;
+    a_y[i] = a_x[i] = 0;
+    a_fb[i] = 0;
+    a_base[i] = nullptr;
+    a_inc[i] = 2;
+    if (MODE == GCD_GEMM_PLAIN) {
+      a_base[i] = (const char*)p.A + (int64_t)m * p.lda * 2 + lc16;
+    } else if (MODE == GCD_GEMM_CONV3X3) {
+      const int hw = p.Ho * p.Wo;
+      const int n = m / hw;
+      const int rem = m - n * hw;
+      a_y[i] = rem / p.Wo;
+      a_x[i] = rem - a_y[i] * p.Wo;
+      a_fb[i] = (int64_t)n * p.Hi * p.Wi;
+    } else {
+      a_y[i] = (m / p.HW) % p.T;
+      a_fb[i] = m;
+    }
+  }
+  auto set_tap = [&](int tap) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (MODE == GCD_GEMM_CONV3X3) {
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        int iy, ix;
+        bool ok;
+        if (p.up) {
+          const int uy = a_y[i] + dy, ux = a_x[i] + dx;
+          ok = uy >= 0 && uy < p.Ho && ux >= 0 && ux < p.Wo;
+          iy = uy >> 1;
+          ix = ux >> 1;
+        } else {
+          iy = a_y[i] * p.stride + dy;
+          ix = a_x[i] * p.stride + dx;
+          ok = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        }
+        a_base[i] = ok ? (const char*)p.A + (a_fb[i] + (int64_t)iy * p.Wi + ix) * p.lda * 2 + lc16
+                       : (const char*)p.zero + lc16;
+        a_inc[i] = ok ? 2 : 0;
+      } else if (MODE == GCD_GEMM_TEMPORAL3) {
+        const int dt = tap - 1;
+        const int tt = a_y[i] + dt;
+        const bool ok = tt >= 0 && tt < p.T;
+        a_base[i] = ok ? (const char*)p.A + (a_fb[i] + (int64_t)dt * p.HW) * p.lda * 2 + lc16
+                       : (const char*)p.zero + lc16;
+        a_inc[i] = ok ? 2 : 0;
+      }
+    }
+  };
+  int a_tap = 0, a_c0 = 0;   // K position of the next A issue (conv modes), block-uniform
+  bool dma_on = true;
+  auto issue_A = [&](int sigma) {
+    if (sigma < S && dma_on) {
+      char* dst = smem + (sigma & 3) * PP_SLOT + wave * 2048;
+      if (MODE == GCD_GEMM_PLAIN) {
+        glds16(a_base[0] + sigma * 64, dst);
+        glds16(a_base[1] + sigma * 64, dst + 1024);
+      } else {
+        glds16(a_base[0] + a_c0 * a_inc[0], dst);
+        glds16(a_base[1] + a_c0 * a_inc[1], dst + 1024);
+      }
+      if (MODE != GCD_GEMM_PLAIN) {
+        a_c0 += 32;
+        if (a_c0 == p.Cin) {
+          a_c0 = 0;
+          ++a_tap;
+          set_tap(a_tap);
+        }
+      }
+    }
+  };
+  // W: group 0 wave w loads pieces 3w .. 3w+2, group 1 wave w' loads 12+2w', 13+2w'
+  const int w_first = grp == 0 ? 3 * wave : 12 + 2 * (wave - 4);
+  const char* w_base[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    int n = n0 + 16 * (w_first + j) + lrow;
+    n = n < p.N ? n : p.N - 1;
+    w_base[j] = (const char*)p.W + (int64_t)n * p.K * 2 + lc16;
+  }
+  auto issue_W = [&](int j, int sigma) {
+    if (sigma < S && dma_on)
+      glds16(w_base[j] + sigma * 64,
+             smem + (sigma & 3) * PP_SLOT + PP_A_BYTES + (w_first + j) * 1024);
+  };
+
+  // ---- fragment read addresses (per lane, within a slot) ----
+  const int swz = (l31 >> 2) & 3;
+  int rdA[2], rdW[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int ch = ((2 * ks + hh) ^ swz) << 4;
+    rdA[ks] = (64 * wm + l31) * 64 + ch;
+    rdW[ks] = PP_A_BYTES + (160 * wn + l31) * 64 + ch;
+  }
+
+  f32x16 acc[5][2];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f16x8 af[2], wf[5];
+  bool reads_on = true;
+  auto load_frags = [&](int slot, int ks) {
+    if ((VAR & 2) && !reads_on) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(af[j]));
+#pragma unroll
+      for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(wf[i]));
+      return;
+    }
+    const char* base = smem + slot * PP_SLOT;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) af[j] = *(const f16x8*)(base + rdA[ks] + j * 2048);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) wf[i] = *(const f16x8*)(base + rdW[ks] + i * 2048);
+  };
+  auto mma = [&]() {
+    if (!(VAR & 8)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    if (!(VAR & 8)) __builtin_amdgcn_s_setprio(0);
+  };
+  bool bars_on = true;
+#define PP_BAR()                                                   \
+  do {                                                             \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    if (!(VAR & 16) || bars_on) __builtin_amdgcn_s_barrier();      \
+    __builtin_amdgcn_sched_barrier(0);                             \
+  } while (0)
+
+  // ---- prologue: sub-tiles 0, 1 and (group 0: the first part of) 2, in steady-state order ----
+  if (MODE != GCD_GEMM_PLAIN) set_tap(0);
+  if (grp == 0) {
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      issue_A(sg);
+      issue_W(0, sg);
+      issue_W(1, sg);
+      issue_W(2, sg);
+    }
+    issue_A(2);
+    issue_W(0, 2);
+  } else {
+#pragma unroll
+    for (int sg = 0; sg < 3; ++sg) {
+      issue_A(sg);
+      issue_W(0, sg);
+      issue_W(1, sg);
+    }
+  }
+  if (S > 2) {
+    PP_VMCNT(8);   // everything of sub-tile 0 has landed (8 newer pieces may still fly)
+  } else {
+    PP_VMCNT(0);
+  }
+  PP_BAR();
+  if (VAR & 1) dma_on = false;
+  if (VAR & 2) {
+    load_frags(0, 0);
+    reads_on = false;
+  }
+  if (VAR & 16) bars_on = false;
+
+  if (grp == 0) {
+    for (int s = 0; s < S; ++s) {
+      const int slot = s & 3;
+      load_frags(slot, 0);
+      issue_W(1, s + 2);
+      issue_W(2, s + 2);
+      PP_BAR();
+      mma();
+      PP_BAR();
+      load_frags(slot, 1);
+      issue_A(s + 3);
+      issue_W(0, s + 3);
+      if (s + 3 < S) {
+        PP_VMCNT(8);   // sub-tile s+1 complete: newer = 5 (s+2) + 3 (first part of s+3)
+      } else {
+        PP_VMCNT(0);
+      }
+      PP_BAR();
+      mma();
+      PP_BAR();
+    }
+    if (!(VAR & 4)) PP_BAR();   // pairs with group 1's last barrier
+  } else {
+    if (!(VAR & 4)) PP_BAR();   // the one-barrier stagger
+    for (int s = 0; s < S; ++s) {
+      const int slot = s & 3;
+      load_frags(slot, 0);
+      issue_A(s + 3);
+      PP_BAR();
+      mma();
+      PP_BAR();
+      load_frags(slot, 1);
+      issue_W(0, s + 3);
+      issue_W(1, s + 3);
+      if (s + 3 < S) {
+        PP_VMCNT(8);   // sub-tile s+1 complete: newer = 4 (s+2) + 4 (s+3)
+      } else {
+        PP_VMCNT(0);
+      }
+      PP_BAR();
+      mma();
+      PP_BAR();
+    }
+  }
+
+  // ---- epilogue: acc[i][j][4g .. 4g+3] = out[m][n .. n+3],
+  //      m = m0 + 64 wm + 32 j + l31,  n = n0 + 160 wn + 32 i + 8 g + 4 hh ----
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + 64 * wm + 32 * j + l31;
+    if (m >= p.M) continue;
+    float sa = p.s_acc, sr1 = p.s_r1, sr2 = p.s_r2;
+    if (p.frame_alpha) {
+      const float al = p.frame_alpha[m / p.rows_per_alpha];
+      sa = 1.0f - al;
+      sr2 = al;
+      if (p.r1_blend) sr1 *= 1.0f - al;
+    }
+    const float* rv = p.rowvec ? p.rowvec + (int64_t)(m / p.rows_per_vec) * p.ld_rowvec : nullptr;
+    if (p.out_kind == GCD_OUT_GEGLU) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int nb = n0 + 160 * wn + 32 * i;   // value rows nb .. nb+15, gate rows nb+16 .. nb+31
+        if (nb >= p.N) continue;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int c = 8 * g + 4 * hh;
+          f32x4 a, gt;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a[e] = acc[i][j][4 * g + e];
+            gt[e] = acc[i][j][8 + 4 * g + e];
+          }
+          if (p.bias) {
+            a += *(const f32x4*)(p.bias + nb + c);
+            gt += *(const f32x4*)(p.bias + nb + 16 + c);
+          }
+          f16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (f16)(a[e] * gelu_f(gt[e]));
+          *(f16x4*)((f16*)p.out + (int64_t)m * p.ldo + (nb >> 1) + c) = o;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + 160 * wn + 32 * i + 8 * g + 4 * hh;
+          if (n >= p.N) continue;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+          if (p.bias) v += *(const f32x4*)(p.bias + n);
+          if (rv) v += *(const f32x4*)(rv + n);
+          v *= sa;
+          if (p.R1) v += sr1 * *(const f32x4*)(p.R1 + (int64_t)m * p.ldr1 + n);
+          if (p.R2) v += sr2 * *(const f32x4*)(p.R2 + (int64_t)m * p.ldr2 + n);
+          if (p.out_kind == GCD_OUT_F32) {
+            *(f32x4*)((float*)p.out + (int64_t)m * p.ldo + n) = v;
+          } else {
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (f16)v[e];
+            *(f16x4*)((f16*)p.out + (int64_t)m * p.ldo + n) = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int MODE, int VAR = 0>
+int launch_pp(const GemmK& k, hipStream_t s) {
+  static bool attr_set = false;
+  auto fn = gemm_pp_kernel<MODE, VAR>;
+  if (!attr_set) {
+    GCD_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      PP_SMEM));
+    attr_set = true;
+  }
+  GemmK kk = k;
+  kk.tiles_m = (k.M + PP_BM - 1) / PP_BM;
+  kk.tiles_n = (k.N + PP_BN - 1) / PP_BN;
+  const int64_t nblk = (int64_t)kk.tiles_m * kk.tiles_n;
+  GCD_CHECK_ARG(nblk > 0 && nblk < (1ll << 31), "gcd_gemm_f16 (pp): bad grid %lld", (long long)nblk);
+  hipLaunchKernelGGL(fn, dim3((unsigned)nblk), dim3(512), PP_SMEM, s, kk);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+// Shapes the ping-pong kernel accepts (the caller has validated the descriptor already).
+bool gcd_gemm_pp_supported(const GemmK& k, int mode) {
+  if (k.K % 32 != 0 || k.N % 4 != 0) return false;
+  if (mode != GCD_GEMM_PLAIN && k.Cin % 32 != 0) return false;
+  if (k.out_kind == GCD_OUT_GEGLU && k.N % 32 != 0) return false;
+  return true;
+}
+
+int gcd_gemm_pp_launch(const GemmK& k, int mode, hipStream_t s) {
+  const int var = gcd_tune_get(GCD_TUNE_GEMM_IMPL) - 32;   // 32 + VAR: ablation builds (PLAIN only)
+  if (var > 0 && mode == GCD_GEMM_PLAIN) {
+    switch (var) {
+      case 1: return launch_pp<GCD_GEMM_PLAIN, 1>(k, s);
+      case 2: return launch_pp<GCD_GEMM_PLAIN, 2>(k, s);
+      case 3: return launch_pp<GCD_GEMM_PLAIN, 3>(k, s);
+      case 4: return launch_pp<GCD_GEMM_PLAIN, 4>(k, s);
+      case 8: return launch_pp<GCD_GEMM_PLAIN, 8>(k, s);
+      case 19: return launch_pp<GCD_GEMM_PLAIN, 19>(k, s);
+      default: break;
+    }
+  }
+  switch (mode) {
+    case GCD_GEMM_PLAIN:
+      return launch_pp<GCD_GEMM_PLAIN>(k, s);
+    case GCD_GEMM_CONV3X3:
+      return launch_pp<GCD_GEMM_CONV3X3>(k, s);
+    default:
+      return launch_pp<GCD_GEMM_TEMPORAL3>(k, s);
+  }
+}

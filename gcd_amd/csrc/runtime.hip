@@ -2,7 +2,10 @@
 // replay of a launch sequence, and HIP events on the caller's stream.
 #include "common.h"
 
+#include <stdlib.h>
 #include <string.h>
+
+#include "gemm_common.h"
 
 static thread_local char g_err[1024] = "";
 
@@ -25,6 +28,29 @@ extern "C" int gcd_device_info(int device, char* name, int cap, int* num_cus, si
   }
   if (num_cus) *num_cus = prop.multiProcessorCount;
   if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+  return 0;
+}
+
+// ---- tuning knobs --------------------------------------------------------------------------------
+static int g_tune[GCD_TUNE_COUNT];
+static bool g_tune_init = false;
+static void tune_init() {
+  if (g_tune_init) return;
+  g_tune_init = true;
+  static const char* env_names[GCD_TUNE_COUNT] = {"GCD_GEMM_IMPL", "GCD_ATTN_IMPL"};
+  for (int i = 0; i < GCD_TUNE_COUNT; ++i) {
+    const char* e = getenv(env_names[i]);
+    g_tune[i] = e ? atoi(e) : 0;
+  }
+}
+int gcd_tune_get(int knob) {
+  tune_init();
+  return (knob >= 0 && knob < GCD_TUNE_COUNT) ? g_tune[knob] : 0;
+}
+extern "C" int gcd_tune_set(int knob, int value) {
+  tune_init();
+  GCD_CHECK_ARG(knob >= 0 && knob < GCD_TUNE_COUNT, "gcd_tune_set: unknown knob %d", knob);
+  g_tune[knob] = value;
   return 0;
 }
 

@@ -37,6 +37,16 @@ const char* gcd_last_error(void);
 /* Fills name (<= cap bytes) with the device's gcnArchName; fails if no HIP device is usable. */
 int gcd_device_info(int device, char* name, int cap, int* num_cus, size_t* hbm_bytes);
 
+/* Kernel-selection knobs (diagnostics / A-B benchmarking; results are identical up to fp32
+ * accumulation order whichever kernel runs).  Initial values come from the environment variables
+ * GCD_GEMM_IMPL / GCD_ATTN_IMPL.
+ *   GCD_TUNE_GEMM_IMPL: 0 = automatic, 1 = general 128-row kernel, 2 = 256x320 ping-pong kernel
+ *   GCD_TUNE_ATTN_IMPL: 0 = automatic, other values select spatial-attention kernel variants   */
+#define GCD_TUNE_GEMM_IMPL 0
+#define GCD_TUNE_ATTN_IMPL 1
+#define GCD_TUNE_COUNT 2
+int gcd_tune_set(int knob, int value);
+
 /* ---- GEMM family (Linear / Conv2d 3x3 / Conv2d 1x1 / Conv3d (3,1,1) as implicit GEMM) ------ */
 /* A-operand addressing modes */
 #define GCD_GEMM_PLAIN 0     /* A is [M, K] fp16, row stride lda                          */
