@@ -5,28 +5,32 @@
 
 // ------------------------------------------------------------------------------------------------
 // y[M,N] = [y +] act_out( act_in(x[M,K]) @ W[N,K]^T + b )   fp32, M <= 32.
-// Workgroup = 4 waves, 16 output columns (4 per wave).  x is staged (activation applied) through
-// LDS in K chunks of 256; lane = (m = lane & 31, k-half = lane >> 5) so that the only cross-lane
-// step is one xor-32 add.  Weight reads are wave-broadcast (L2-resident, 100s of KB per layer).
+// A skinny GEMM that only has to stream W (up to 190 MB for the 44 stacked emb_layers) at HBM rate:
+// workgroup = 4 waves x 4 output columns; x is staged (activation applied) through LDS in K chunks
+// of 256; a lane owns (column lane >> 4, k-slot lane & 15): the 16 lanes of a column read 256
+// contiguous bytes of its W row per instruction and keep MMAX row accumulators, the x operands come
+// from LDS as 16-byte reads that are broadcast over the 4 columns.  One 16-lane reduction at the end.
 // ------------------------------------------------------------------------------------------------
 #define SM_KC 256
 #define SM_LDX (SM_KC + 4)
 
-__global__ __launch_bounds__(256) void linear_smallm_kernel(const float* __restrict__ x, int64_t ldx,
+template <int MMAX>
+__global__ __launch_bounds__(256, 2) void linear_smallm_kernel(const float* __restrict__ x, int64_t ldx,
                                                             const float* __restrict__ W,
                                                             const float* __restrict__ b,
                                                             float* __restrict__ y, int64_t ldy, int M,
                                                             int N, int K, int flags) {
-  __shared__ __attribute__((aligned(16))) float xs[32 * SM_LDX];
+  __shared__ __attribute__((aligned(16))) float xs[MMAX * SM_LDX];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int m = lane & 31, kh = lane >> 5;
-  const int n0 = blockIdx.x * 16 + wave * 4;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int kp = lane & 15;
+  const int n = blockIdx.x * 16 + wave * 4 + (lane >> 4);
+  const float* wrow = W + (int64_t)(n < N ? n : N - 1) * K;
+  float acc[MMAX];
+#pragma unroll
+  for (int m = 0; m < MMAX; ++m) acc[m] = 0.f;
   for (int kc = 0; kc < K; kc += SM_KC) {
     // stage x[:, kc:kc+256] (zero padded) with the input activation applied
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = t + 256 * i;
+    for (int idx = t; idx < MMAX * 64; idx += 256) {
       const int mm = idx >> 6, kv = (idx & 63) * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (mm < M && kc + kv < K) {
@@ -39,39 +43,45 @@ __global__ __launch_bounds__(256) void linear_smallm_kernel(const float* __restr
       *(f32x4*)(xs + mm * SM_LDX + kv) = v;
     }
     __syncthreads();
+    f32x4 wv[4];
 #pragma unroll
-    for (int nn = 0; nn < 4; ++nn) {
-      const int n = n0 + nn;
-      if (n < N) {
-        const float* wr = W + (int64_t)n * K + kc + kh * 128;
-        const float* xr = xs + m * SM_LDX + kh * 128;
-        float a = acc[nn];
-#pragma unroll 8
-        for (int i = 0; i < 32; ++i) {
-          if (kc + kh * 128 + i * 4 < K) {
-            const f32x4 wv = *(const f32x4*)(wr + i * 4);
-            const f32x4 xv = *(const f32x4*)(xr + i * 4);
-            a = fmaf(xv[0], wv[0], a);
-            a = fmaf(xv[1], wv[1], a);
-            a = fmaf(xv[2], wv[2], a);
-            a = fmaf(xv[3], wv[3], a);
-          }
-        }
-        acc[nn] = a;
+    for (int i = 0; i < 4; ++i) {
+      const int k = kc + 64 * i + kp * 4;
+      wv[i] = k < K ? *(const f32x4*)(wrow + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* xr = xs + 64 * i + kp * 4;
+#pragma unroll
+      for (int m = 0; m < MMAX; ++m) {
+        const f32x4 xv = *(const f32x4*)(xr + m * SM_LDX);
+        float a = acc[m];
+        a = fmaf(xv[0], wv[i][0], a);
+        a = fmaf(xv[1], wv[i][1], a);
+        a = fmaf(xv[2], wv[i][2], a);
+        a = fmaf(xv[3], wv[i][3], a);
+        acc[m] = a;
       }
     }
     __syncthreads();
   }
+  // reduce over the 16 k-slots of a column; afterwards every lane of the group holds the totals
 #pragma unroll
-  for (int nn = 0; nn < 4; ++nn) {
-    const float tot = acc[nn] + __shfl_xor(acc[nn], 32);
-    const int n = n0 + nn;
-    if (kh == 0 && m < M && n < N) {
-      float v = tot + (b ? b[n] : 0.f);
-      if (flags & 2) v = silu_f(v);
-      float* dst = y + (int64_t)m * ldy + n;
-      if (flags & 4) v += *dst;
-      *dst = v;
+  for (int m = 0; m < MMAX; ++m) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc[m] += __shfl_xor(acc[m], o);
+  }
+  if (n < N) {
+    const float bn = b ? b[n] : 0.f;
+#pragma unroll
+    for (int m = 0; m < MMAX; ++m) {
+      if ((m & 15) == kp && m < M) {   // lane kp of the group writes rows kp and kp + 16
+        float v = acc[m] + bn;
+        if (flags & 2) v = silu_f(v);
+        float* dst = y + (int64_t)m * ldy + n;
+        if (flags & 4) v += *dst;
+        *dst = v;
+      }
     }
   }
 }
@@ -84,8 +94,14 @@ extern "C" int gcd_linear_smallm_f32(const float* x, int64_t ldx, const float* W
   GCD_CHECK_ARG(N >= 1 && K >= 4 && K % 4 == 0 && ldx % 4 == 0,
                 "gcd_linear_smallm_f32: N=%d K=%d ldx=%lld (K, ldx must be multiples of 4)", N, K,
                 (long long)ldx);
-  hipLaunchKernelGGL(linear_smallm_kernel, dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, x,
-                     ldx, W, b, y, ldy, M, N, K, act_flags);
+  const dim3 grid((N + 15) / 16), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (M <= 4)
+    hipLaunchKernelGGL(linear_smallm_kernel<4>, grid, block, 0, s, x, ldx, W, b, y, ldy, M, N, K, act_flags);
+  else if (M <= 16)
+    hipLaunchKernelGGL(linear_smallm_kernel<16>, grid, block, 0, s, x, ldx, W, b, y, ldy, M, N, K, act_flags);
+  else
+    hipLaunchKernelGGL(linear_smallm_kernel<32>, grid, block, 0, s, x, ldx, W, b, y, ldy, M, N, K, act_flags);
   GCD_CHECK_LAUNCH();
   return 0;
 }

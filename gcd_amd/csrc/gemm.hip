@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmK p) {
           }
           f16x4 o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (f16)(a[r] * gelu_f(g[r]));
+          for (int r = 0; r < 4; ++r) o[r] = (f16)(a[r] * gelu_fast(g[r]));
           *(f16x4*)((f16*)p.out + (int64_t)m * p.ldo + (nt >> 1) + nq) = o;
         }
       }
@@ -333,7 +333,7 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
   bool use_pp = false;
   if (impl != 1 && gcd_gemm_pp_supported(k, d->mode)) {
     const int64_t tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 319) / 320);
-    use_pp = impl >= 2 || (tiles >= 192 && d->N >= 160);
+    use_pp = impl >= 2 || (impl == 0 && tiles >= 192 && d->N >= 160);
   }
 
   switch (d->mode) {

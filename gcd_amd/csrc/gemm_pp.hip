@@ -302,71 +302,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
     }
   }
 
-  // ---- epilogue: acc[i][j][4g .. 4g+3] = out[m][n .. n+3],
-  //      m = m0 + 64 wm + 32 j + l31,  n = n0 + 160 wn + 32 i + 8 g + 4 hh ----
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int m = m0 + 64 * wm + 32 * j + l31;
-    if (m >= p.M) continue;
-    float sa = p.s_acc, sr1 = p.s_r1, sr2 = p.s_r2;
-    if (p.frame_alpha) {
-      const float al = p.frame_alpha[m / p.rows_per_alpha];
-      sa = 1.0f - al;
-      sr2 = al;
-      if (p.r1_blend) sr1 *= 1.0f - al;
-    }
-    const float* rv = p.rowvec ? p.rowvec + (int64_t)(m / p.rows_per_vec) * p.ld_rowvec : nullptr;
-    if (p.out_kind == GCD_OUT_GEGLU) {
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const int nb = n0 + 160 * wn + 32 * i;   // value rows nb .. nb+15, gate rows nb+16 .. nb+31
-        if (nb >= p.N) continue;
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const int c = 8 * g + 4 * hh;
-          f32x4 a, gt;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            a[e] = acc[i][j][4 * g + e];
-            gt[e] = acc[i][j][8 + 4 * g + e];
-          }
-          if (p.bias) {
-            a += *(const f32x4*)(p.bias + nb + c);
-            gt += *(const f32x4*)(p.bias + nb + 16 + c);
-          }
-          f16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (f16)(a[e] * gelu_f(gt[e]));
-          *(f16x4*)((f16*)p.out + (int64_t)m * p.ldo + (nb >> 1) + c) = o;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = n0 + 160 * wn + 32 * i + 8 * g + 4 * hh;
-          if (n >= p.N) continue;
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-          if (p.bias) v += *(const f32x4*)(p.bias + n);
-          if (rv) v += *(const f32x4*)(rv + n);
-          v *= sa;
-          if (p.R1) v += sr1 * *(const f32x4*)(p.R1 + (int64_t)m * p.ldr1 + n);
-          if (p.R2) v += sr2 * *(const f32x4*)(p.R2 + (int64_t)m * p.ldr2 + n);
-          if (p.out_kind == GCD_OUT_F32) {
-            *(f32x4*)((float*)p.out + (int64_t)m * p.ldo + n) = v;
-          } else {
-            f16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (f16)v[e];
-            *(f16x4*)((f16*)p.out + (int64_t)m * p.ldo + n) = o;
-          }
-        }
-      }
-    }
-  }
+  // ---- epilogue (gemm_common.h): LDS-transposed, 128-byte-row global accesses.  Every wave is
+  //      past its last fragment read of the ring (see the barrier structure above). ----
+  gcd_epilogue_64x160<(VAR >> 6)>(p, acc, m0 + 64 * wm, n0 + 160 * wn, lane, smem + wave * GCD_EPI_STAGE_BYTES);
 }
 
 template <int MODE, int VAR = 0>
@@ -408,6 +346,11 @@ int gcd_gemm_pp_launch(const GemmK& k, int mode, hipStream_t s) {
       case 4: return launch_pp<GCD_GEMM_PLAIN, 4>(k, s);
       case 8: return launch_pp<GCD_GEMM_PLAIN, 8>(k, s);
       case 19: return launch_pp<GCD_GEMM_PLAIN, 19>(k, s);
+      // pure-MFMA loop (19) + epilogue experiments (EV << 6)
+      case 19 + 64: return launch_pp<GCD_GEMM_PLAIN, 19 + 64>(k, s);      // no residual loads
+      case 19 + 128: return launch_pp<GCD_GEMM_PLAIN, 19 + 128>(k, s);    // no stores
+      case 19 + 192: return launch_pp<GCD_GEMM_PLAIN, 19 + 192>(k, s);    // neither
+      case 1024: return launch_pp<GCD_GEMM_PLAIN, 1024>(k, s);            // transposed epilogue forced
       default: break;
     }
   }

@@ -12,26 +12,29 @@
 
 // ------------------------------------------------------------------------------------------------
 // GroupNorm statistics
-// grid = (nchunks, ninst); block 256 = 4 row-lanes x 64 column-lanes.
+// grid = (nchunks, ninst).  A thread keeps ONE float4 column for the whole chunk (block = txw
+// columns x rpp rows, txw = C/4 or C/8, so no lane idles on a ragged column tail): its fp64
+// sum / sum-of-squares stay in registers, the block then merges them per group with LDS atomics.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_stats_partial_kernel(
+__global__ __launch_bounds__(512) void gn_stats_partial_kernel(
     const float* __restrict__ x1, int64_t ld1, int C1, const float* __restrict__ x2, int64_t ld2,
-    int C2, int64_t rows_per_inst, int rows_per_chunk, double* __restrict__ partial) {
+    int C2, int64_t rows_per_inst, int rows_per_chunk, int txw, int kpass,
+    double* __restrict__ partial) {
   __shared__ double acc[32][2];
   const int t = threadIdx.x;
   if (t < 64) acc[t >> 1][t & 1] = 0.0;
   __syncthreads();
   const int C = C1 + C2;
   const int cg = C / 32;
-  const int cv4 = C >> 2;
   const int inst = blockIdx.y, chunk = blockIdx.x;
   const int64_t r0 = (int64_t)chunk * rows_per_chunk;
   int64_t r1 = r0 + rows_per_chunk;
   if (r1 > rows_per_inst) r1 = rows_per_inst;
   const int64_t base = (int64_t)inst * rows_per_inst;
-  const int tx = t & 63, ty = t >> 6;
-  for (int cv = tx; cv < cv4; cv += 64) {
-    const int c = cv * 4;
+  const int tx = t % txw, ty = t / txw;
+  const int rpp = blockDim.x / txw;
+  for (int kp = 0; kp < kpass; ++kp) {
+    const int c = (tx + kp * txw) * 4;
     const float* src;
     int64_t ld;
     if (c < C1) {
@@ -42,7 +45,19 @@ __global__ __launch_bounds__(256) void gn_stats_partial_kernel(
       ld = ld2;
     }
     double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
-    for (int64_t r = r0 + ty; r < r1; r += 4) {
+    // two rows in flight per thread
+    int64_t r = r0 + ty;
+    for (; r + rpp < r1; r += 2 * rpp) {
+      const f32x4 v = *(const f32x4*)(src + (base + r) * ld);
+      const f32x4 w = *(const f32x4*)(src + (base + r + rpp) * ld);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double d = (double)v[e], f = (double)w[e];
+        s[e] += d + f;
+        ss[e] += d * d + f * f;
+      }
+    }
+    if (r < r1) {
       const f32x4 v = *(const f32x4*)(src + (base + r) * ld);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -72,15 +87,20 @@ __global__ __launch_bounds__(256) void gn_stats_partial_kernel(
   }
 }
 
-// grid = ninst, block = 64: lane t -> (group t>>1, component t&1)
-__global__ __launch_bounds__(64) void gn_stats_final_kernel(const double* __restrict__ partial,
-                                                            int nchunks, double count, float eps,
-                                                            float* __restrict__ stats) {
-  const int inst = blockIdx.x, t = threadIdx.x;
+// grid = ninst, block = 256: thread (part = t >> 6, comp = t & 63) sums every 4th chunk; lanes
+// (2g, 2g+1) of comp hold (sum, sumsq) of group g.
+__global__ __launch_bounds__(256) void gn_stats_final_kernel(const double* __restrict__ partial,
+                                                             int nchunks, double count, float eps,
+                                                             float* __restrict__ stats) {
+  __shared__ double red[4][64];
+  const int inst = blockIdx.x, t = threadIdx.x & 63, part = threadIdx.x >> 6;
   double a = 0.0;
   const double* src = partial + (int64_t)inst * nchunks * 64 + t;
-  for (int i = 0; i < nchunks; ++i) a += src[(int64_t)i * 64];
-  // lanes (2g, 2g+1) hold (sum, sumsq) of group g
+  for (int i = part; i < nchunks; i += 4) a += src[(int64_t)i * 64];
+  red[part][t] = a;
+  __syncthreads();
+  if (part != 0) return;
+  a = red[0][t] + red[1][t] + red[2][t] + red[3][t];
   const double other = __shfl_xor(a, 1);
   const double sum = (t & 1) ? other : a;
   const double sq = (t & 1) ? a : other;
@@ -107,11 +127,18 @@ extern "C" int gcd_groupnorm_stats(const float* x1, int64_t ld1, int C1, const f
   const int ninst = (int)(M / rows_per_inst);
   const int rpc = (int)((rows_per_inst + nchunks - 1) / nchunks);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(nchunks, ninst), dim3(256), 0, s, x1, ld1, C1, x2,
-                     ld2, C2, rows_per_inst, rpc, partial);
+  // thread <-> float4-column map: all C/4 columns at once when they fit a workgroup, else 2..4 passes
+  const int cv4 = C / 4;
+  int kpass = 1;
+  while (cv4 % kpass != 0 || cv4 / kpass > 512) ++kpass;
+  const int txw = cv4 / kpass;
+  int rpp = 320 / txw;
+  if (rpp < 1) rpp = 1;
+  hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(nchunks, ninst), dim3(txw * rpp), 0, s, x1, ld1, C1,
+                     x2, ld2, C2, rows_per_inst, rpc, txw, kpass, partial);
   GCD_CHECK_LAUNCH();
   const double count = (double)rows_per_inst * (double)(C / 32);
-  hipLaunchKernelGGL(gn_stats_final_kernel, dim3(ninst), dim3(64), 0, s, partial, nchunks, count,
+  hipLaunchKernelGGL(gn_stats_final_kernel, dim3(ninst), dim3(256), 0, s, partial, nchunks, count,
                      eps, stats);
   GCD_CHECK_LAUNCH();
   return 0;

@@ -66,7 +66,7 @@ extern "C" int gcd_graph_end_capture(void* stream, void** graph_exec_out) {
   GCD_CHECK_HIP(hipStreamEndCapture((hipStream_t)stream, &graph));
   hipGraphExec_t exec = nullptr;
   hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  hipGraphDestroy(graph);
+  (void)hipGraphDestroy(graph);
   if (e != hipSuccess) {
     gcd_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
     return 1;

@@ -277,8 +277,8 @@ class UNetEngine:
         ws = self.ws
         M = x1.shape[0]
         C = x1.shape[1] + (0 if x2 is None else x2.shape[1])
-        nch = ops.gn_nchunks(rows)
         ninst = M // rows
+        nch = ops.gn_nchunks(rows, ninst)
         partial = ws.alloc((ninst * nch * 64,), torch.float64)
         stats = ws.alloc((ninst * 64,), torch.float32)
         ops.groupnorm_stats(x1, x2, rows, eps, partial, stats, nch)
@@ -460,22 +460,33 @@ class UNetEngine:
         ws.release(emb)
         return emb_all
 
-    def _cross_attention_vectors(self, context, st):
+    def _cross_attention_vectors(self, context_src, context, st):
         """attn2 with a single key: out = to_out(to_v(ctx)) per frame (spatial, attention.py:300-344)
-        or per clip from the first frame's context (temporal, video_attention.py:244-253)."""
-        P, ws = self.packed, self.ws
+        or per clip from the first frame's context (temporal, video_attention.py:244-253).
+
+        The vectors depend on the context and the weights only, not on the noise level, so they are
+        kept across calls for as long as the caller passes the same (unmodified) context tensor —
+        every step of a sampling loop after the first (keyed on storage address + torch's in-place
+        version counter; `pack()` clears the cache when the weights change)."""
+        P = self.packed
         N, T = st["N"], st["T"]
-        v_all = ws.alloc((N, P["ca_total"]), torch.float32)
+        key = (context_src.data_ptr(), context_src._version, tuple(context_src.shape),
+               context_src.dtype, N, T)
+        hit = P.get("ca_cache")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        dev = context.device
+        v_all = torch.empty((N, P["ca_total"]), dtype=torch.float32, device=dev)
         ops.linear_smallm(context, P["ca_wv"], None, v_all)
         outs = []
         for m in P["ca_mods"]:
             src = v_all[:, m["off"]:m["off"] + m["C"]]
             if m["temporal"]:
                 src = src[::T]
-            o = ws.alloc((src.shape[0], m["C"]), torch.float32)
+            o = torch.empty((src.shape[0], m["C"]), dtype=torch.float32, device=dev)
             ops.linear_smallm(src, m["wo"], m["bo"], o)
             outs.append(o)
-        ws.release(v_all)
+        P["ca_cache"] = (key, outs, v_all)
         return outs
 
     # ------------------------------------------------------------------------------------------
@@ -531,7 +542,7 @@ class UNetEngine:
         ctx2d = context.detach().float().reshape(N, -1).contiguous()
         y32 = y.detach().float().contiguous()
         st["emb_all"] = self._embeddings(timesteps, y32, st)
-        st["ca"] = self._cross_attention_vectors(ctx2d, st)
+        st["ca"] = self._cross_attention_vectors(context, ctx2d, st)
 
         M = N * H * W
         xin = ws.alloc((M, CIN_PAD), torch.float16)

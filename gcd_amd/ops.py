@@ -143,8 +143,11 @@ def linear_smallm(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], y
     return y
 
 
-def gn_nchunks(rows_per_inst: int) -> int:
-    return max(1, min(256, (rows_per_inst + 63) // 64))
+def gn_nchunks(rows_per_inst: int, ninst: int = 1) -> int:
+    """Row chunks per GroupNorm instance for the statistics pass: ~1500 workgroups over the whole
+    launch (6 per CU), never less than 64 rows per chunk, at most 256 chunks per instance."""
+    want = max(1, -(-1536 // max(1, ninst)))
+    return max(1, min(256, want, (rows_per_inst + 63) // 64))
 
 
 def groupnorm_stats(x1, x2, rows_per_inst: int, eps: float, partial: torch.Tensor,

@@ -249,7 +249,19 @@ int main(int argc, char** argv) {
         if (it >= 2) t.push_back(ms * 1e3f);
       }
       std::sort(t.begin(), t.end());
-      printf("    impl %3d: %9.1f us %8.1f TF/s\n", impl, t[t.size() / 2], fl / t[t.size() / 2] * 1e-6);
+      float xd = -1.f;
+      if (impl < 32) {   // a product kernel: check it against the general kernel's output
+        CK(hipMemsetAsync(res, 0, 8, st));
+        if (f16out) cmp_kernel<f16><<<1024, 256, 0, st>>>((const f16*)o[1], (const f16*)o[0], o_n, res);
+        else cmp_kernel<float><<<1024, 256, 0, st>>>((const float*)o[1], (const float*)o[0], o_n, res);
+        unsigned hr[2];
+        CK(hipMemcpyAsync(hr, res, 8, hipMemcpyDeviceToHost, st));
+        CK(hipStreamSynchronize(st));
+        memcpy(&xd, &hr[0], 4);
+        if (xd > (f16out ? 4e-3 : 2e-4) * fmax(mb, 1.0f)) ++bad;
+      }
+      printf("    impl %3d: %9.1f us %8.1f TF/s  (%.2fx legacy)  maxdiff %9.2e\n", impl, t[t.size() / 2],
+             fl / t[t.size() / 2] * 1e-6, us[0] / t[t.size() / 2], xd);
     }
     const double tol = (f16out ? 4e-3 : 2e-4) * fmax(mb, 1.0f);
     const bool ok = md <= tol && (hostchk < 0 || hostchk <= (f16out ? 8e-3 : 1e-3) * fmax(mb, 1.0f));
