@@ -11,7 +11,7 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libgcd_amd.so"
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # GEMM modes / output kinds (mirror include/gcd_amd.h)
 GEMM_PLAIN, GEMM_CONV3X3, GEMM_TEMPORAL3 = 0, 1, 2
@@ -55,7 +55,7 @@ SIGNATURES = {
     "gcd_layernorm_f16": (_i, [_vp, _i64, _i64, _i, _vp, _vp, _f, _vp, _i64, _i, _vp, _i64, _vp,
                                _i64, _vp]),
     "gcd_attn_transpose_v": (_i, [_vp, _i64, _i, _i, _i, _vp, _i, _vp]),
-    "gcd_attn_spatial_f16": (_i, [_vp, _i64, _vp, _i, _vp, _i64, _i, _i, _i, _vp]),
+    "gcd_attn_spatial_f16": (_i, [_vp, _i64, _vp, _i, _vp, _i64, _i, _i, _i, _i, _vp]),
     "gcd_attn_temporal_f16": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
     "gcd_pack_input": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp]),
     "gcd_unpack_output": (_i, [_vp, _i64, _vp, _i, _i, _i, _vp]),

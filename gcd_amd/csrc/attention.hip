@@ -12,12 +12,22 @@
 //  * gcd_attn_transpose_v: builds the V^T[head][d][token] operand (zero padded to 64 keys).
 //  * gcd_attn_temporal_f16: attention over the T <= 16 frames of one pixel; 0.05 % of the FLOPs and
 //    HBM-bound, so it runs on the VALU (v_dot2_f32_f16 / v_fma_mix) with 16 lanes per problem.
-#include "common.h"
+#include "gemm_common.h"
 
 #define LOG2E_F 1.4426950408889634f
 
+// max(a, b, c) as ONE instruction.  fmaxf on MFMA outputs makes hipcc emit a canonicalising
+// v_max_f32 x, x per operand (IEEE maxNum quieting), which tripled the row-max cost of a VALU-bound
+// kernel; v_max3_f32 quiets NaNs in hardware.
+__device__ __forceinline__ float max3_f(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // ------------------------------------------------------------------------------------------------
-// V transpose: qkv[(f*S+s)*ld + 2C + h*64 + d] -> vt[((f*heads+h)*64 + d)*S_pad + s]
+// V transpose: qkv[(f*S+s)*ld + 2C + h*64 + d] -> vt[((f*heads+h)*64 + d)*S_pad + perm(s)],
+// perm swaps the two middle quads of every 16-key group (see the kernel)
 // grid (S_pad/64, heads, frames), block 256
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_transpose_v_kernel(const f16* __restrict__ qkv,
@@ -38,10 +48,12 @@ __global__ __launch_bounds__(256) void attn_transpose_v_kernel(const f16* __rest
   __syncthreads();
   const int d = t >> 2, tg = (t & 3) * 16;
   f16x8 o0, o1;
+  // within each group of 16 keys the two middle quads are swapped (keys 0-3, 8-11, 4-7, 12-15):
+  // the 8 keys a lane of the P V MFMA needs, (r&3) + 8(r>>2) + 4(lane>>5), are then 16 contiguous bytes
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    o0[e] = tile[tg + e][d];
-    o1[e] = tile[tg + 8 + e][d];
+    o0[e] = tile[tg + (e < 4 ? e : e + 4)][d];
+    o1[e] = tile[tg + (e < 4 ? e + 4 : e + 8)][d];
   }
   f16* dst = vt + (((int64_t)f * heads + h) * 64 + d) * S_pad + s0 + tg;
   *(f16x8*)dst = o0;
@@ -62,20 +74,49 @@ extern "C" int gcd_attn_transpose_v(const void* qkv, int64_t ld, int frames, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// Spatial flash attention.  grid (ceil(S/128), heads, frames), block 256.
+// Spatial flash attention.  grid (ceil(S/128), heads, frames) remapped XCD-aware, block 256.
+//
+// Measured facts that shaped the loop (tools/attn_bench ablations, profiles/r01_attention_*): a SIMD
+// issues roughly one instruction per 4 cycles whatever the mix and a transcendental keeps its unit
+// for 16, so with 3 waves per SIMD the kernel is bound by INSTRUCTION COUNT per 32 x 64 score block
+// (~240 before), not by MFMA, LDS or HBM.  Hence:
+//   * PRESCALED: the softmax scale times log2(e) is folded into W_q when the weights are packed
+//     (fp32 multiply before the one fp16 rounding), so a score is already an exp2 argument;
+//   * the running reference max is subtracted BY THE MATRIX PIPE: Q K^T accumulates onto a register
+//     block holding -m_ref, and m_ref only moves when a tile's max exceeds it by more than
+//     GCD_ATTN_THR (P <= 2^THR, exact in fp16's range; O and the denominator are rescaled by the same
+//     factor on that rare path), so the steady state is max3 + exp2 + cvt per score — no subtract;
+//   * the denominator comes from 4 extra MFMAs against a block of ones instead of 32 adds;
+//   * 3-stage K / V^T ring filled by LDS-DMA two tiles ahead, counted vmcnt(4), one barrier per tile.
 // ------------------------------------------------------------------------------------------------
+#define GCD_ATTN_THR 8.0f
+
+template <bool PRESCALED>
 __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restrict__ qkv,
                                                               int64_t ld, const f16* __restrict__ vt,
                                                               int S_pad, f16* __restrict__ out,
                                                               int64_t ldo, int S, int heads,
-                                                              float c /* scale * log2(e) */) {
-  // stage = [K tile 64 keys x 64 d | V^T tile 64 d x 64 keys], 8 KB each, two stages
-  __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+                                                              int nqb, float c /* scale * log2(e) */) {
+  // stage = [K tile 64 keys x 64 d | V^T tile 64 d x 64 keys], 8 KB each, three stages
+  __shared__ __attribute__((aligned(16))) char smem[3 * 16384];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  const int head = blockIdx.y, frame = blockIdx.z;
+  // XCD-aware block order: every XCD owns a contiguous range of (frame, head, q-block) triples, so the
+  // q-blocks of one (frame, head) share that XCD's L2 copy of its K / V (2.4 MB at 72 x 128 tokens).
+  int qb, head, frame;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    qb = L % nqb;
+    const int fh = L / nqb;
+    head = fh % heads;
+    frame = fh / heads;
+  }
   const int C = heads * 64;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = qb * 128 + wave * 32;
 
   // Q^T fragments (B operand): query l31, d = 16 ks + 8 half + j
   f16x8 qf[4];
@@ -92,45 +133,78 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
   const int cl = (t & 7) ^ ((prow >> 1) & 7);
   const f16* kbase = qkv + (int64_t)frame * S * ld + C + head * 64 + cl * 8;
   const f16* vbase = vt + (((int64_t)frame * heads + head) * 64) * S_pad + cl * 8;
+  const int ntiles = (S + 63) >> 6;
 
-  auto stage = [&](int kv0, int buf) {
-    char* Ks = smem + buf * 16384;
-    char* Vs = Ks + 8192;
+  auto stage = [&](int kt) {
+    if (kt < ntiles) {
+      const int kv0 = kt << 6;
+      char* Ks = smem + (kt % 3) * 16384;
+      char* Vs = Ks + 8192;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = prow + 32 * i;
-      int key = kv0 + row;
-      key = key < S ? key : S - 1;
-      glds16(kbase + (int64_t)key * ld, Ks + (i * 256 + wave * 64) * 16);
-      glds16(vbase + (int64_t)row * S_pad + kv0, Vs + (i * 256 + wave * 64) * 16);
+      for (int i = 0; i < 2; ++i) {
+        const int row = prow + 32 * i;
+        int key = kv0 + row;
+        key = key < S ? key : S - 1;
+        glds16(kbase + (int64_t)key * ld, Ks + (i * 256 + wave * 64) * 16);
+        glds16(vbase + (int64_t)row * S_pad + kv0, Vs + (i * 256 + wave * 64) * 16);
+      }
     }
   };
 
-  f32x16 o0, o1;
+  // o0 / o1: O^T rows d = 0-31 / 32-63; o2: the softmax denominator (V^T row block of ones).
+  f32x16 o0, o1, o2, nm;   // nm: -m_ref of this lane's query in all 16 registers (MFMA C operand)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  for (int r = 0; r < 16; ++r) o0[r] = o1[r] = o2[r] = nm[r] = 0.f;
+  const f16x8 ones = {(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
+  // per-lane LDS offsets of the K / V^T fragments within a stage (V^T = +8192, rows 32-63 = +4096)
+  int foff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) foff[ks] = lds_tile_off(l31, 2 * ks + half);
 
-  const int ntiles = (S + 63) >> 6;
-  stage(0, 0);
+  stage(0);
+  stage(1);
   for (int kt = 0; kt < ntiles; ++kt) {
-    const int buf = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < ntiles) stage((kt + 1) << 6, buf ^ 1);
-    const char* Ks = smem + buf * 16384;
+    // tile kt has landed (my pieces; tile kt+1's 4 may still fly) -> barrier -> everybody's have,
+    // and every wave is done reading tile kt-1, whose stage takes tile kt+2
+    if (kt + 1 < ntiles) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    stage(kt + 2);
+    const char* Ks = smem + (kt % 3) * 16384;
     const char* Vs = Ks + 8192;
 
-    // ---- S^T = K Q^T : two 32-key sub-tiles ----
-    f32x16 s0, s1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
+    f16x8 kf[8];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const f16x8 k0 = *(const f16x8*)(Ks + lds_tile_off(l31, 2 * ks + half));
-      const f16x8 k1 = *(const f16x8*)(Ks + lds_tile_off(32 + l31, 2 * ks + half));
-      s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[ks], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[ks], s1, 0, 0, 0);
+      kf[2 * ks] = *(const f16x8*)(Ks + foff[ks]);
+      kf[2 * ks + 1] = *(const f16x8*)(Ks + foff[ks] + 4096);
+    }
+    // ---- S^T - m_ref = K Q^T + nm : two 32-key sub-tiles ----
+    f32x16 s0, s1;
+    s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[0], nm, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qf[0], nm, 0, 0, 0);
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks) {
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[2 * ks], qf[ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[2 * ks + 1], qf[ks], s1, 0, 0, 0);
+    }
+    // ---- V^T fragments: issued now, consumed after the softmax (their latency hides under it) ----
+    f16x8 vf[8];   // vf[2*c2 + dt]: d rows 32 dt + l31, keys 16 c2 + {0-3, 8-11} + 4 half
+#pragma unroll
+    for (int c2 = 0; c2 < 4; ++c2) {
+      vf[2 * c2] = *(const f16x8*)(Vs + foff[c2]);
+      vf[2 * c2 + 1] = *(const f16x8*)(Vs + foff[c2] + 4096);
+    }
+    if (!PRESCALED) {
+      // scores arrive in natural units: s <- s*c + nm*(1 - c)   (nm is already in exp2 units)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = fmaf(s0[r] - nm[0], c, nm[0]);
+        s1[r] = fmaf(s1[r] - nm[0], c, nm[0]);
+      }
     }
     // register r of a sub-tile holds key (r&3) + 8*(r>>2) + 4*half
     if ((kt << 6) + 64 > S) {
@@ -142,57 +216,48 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         if (key + 32 >= S) s1[r] = -INFINITY;
       }
     }
-    // ---- online softmax (per query = per lane column) ----
-    float mx = fmaxf(s0[0], s1[0]);
+    // ---- tile max relative to m_ref (per query = per lane column, both halves) ----
+    float mx = max3_f(s0[0], s1[0], s0[1]);
+    mx = max3_f(mx, s1[1], s0[2]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    m_run = m_new;
-    const float mc = m_new * c;
-    float psum = 0.f;
-    f16x8 pf[4];  // pf[2*kt2 + s] = P^T fragment (B operand) for k-step s of sub-tile kt2
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float p0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));
-      const float p1 = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc));
-      psum += p0 + p1;
-      pf[r >> 3][r & 7] = (f16)p0;
-      pf[2 + (r >> 3)][r & 7] = (f16)p1;
+    for (int r = 2; r < 15; ++r) mx = max3_f(mx, s1[r], s0[r + 1]);
+    mx = fmaxf(mx, s1[15]);
+    {
+      const unsigned mu = __float_as_uint(mx);
+      const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     }
-    l_run = l_run * alpha + psum;
+    // ---- rare path: move the reference (always on the first tile, which defines it) ----
+    if (kt == 0 || __any(mx > GCD_ATTN_THR)) {
+      const float delta = (kt == 0 || mx > GCD_ATTN_THR) ? mx : 0.f;
+      const float alpha = kt == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);   // O is still 0 on tile 0
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      o0[r] *= alpha;
-      o1[r] *= alpha;
-    }
-    // ---- O^T += V^T P^T ----
-#pragma unroll
-    for (int kt2 = 0; kt2 < 2; ++kt2) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int ch = 4 * kt2 + 2 * s;
-        f16x8 a0, a1;
-        {
-          const f16x4 lo = *(const f16x4*)(Vs + lds_tile_off(l31, ch) + 8 * half);
-          const f16x4 hi = *(const f16x4*)(Vs + lds_tile_off(l31, ch + 1) + 8 * half);
-          a0 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
-        {
-          const f16x4 lo = *(const f16x4*)(Vs + lds_tile_off(32 + l31, ch) + 8 * half);
-          const f16x4 hi = *(const f16x4*)(Vs + lds_tile_off(32 + l31, ch + 1) + 8 * half);
-          a1 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, pf[2 * kt2 + s], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, pf[2 * kt2 + s], o1, 0, 0, 0);
+      for (int r = 0; r < 16; ++r) {
+        s0[r] -= delta;
+        s1[r] -= delta;
+        o0[r] *= alpha;
+        o1[r] *= alpha;
+        o2[r] *= alpha;
+        nm[r] -= delta;
       }
+    }
+    f16x8 pf[4];  // pf[c2] = P^T fragment (B operand) for the 16 keys 16 c2 .. 16 c2 + 15
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      pf[r >> 3][r & 7] = (f16)__builtin_amdgcn_exp2f(s0[r]);
+      pf[2 + (r >> 3)][r & 7] = (f16)__builtin_amdgcn_exp2f(s1[r]);
+    }
+    // ---- O^T += V^T P^T, denominator += 1 P^T ----
+#pragma unroll
+    for (int c2 = 0; c2 < 4; ++c2) {
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[2 * c2], pf[c2], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[2 * c2 + 1], pf[c2], o1, 0, 0, 0);
+      o2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[c2], o2, 0, 0, 0);
     }
   }
 
   // ---- normalise and store: o{0,1}[r] is O[query l31][d = 32 dt + (r&3) + 8 (r>>2) + 4 half] ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_tot;
+  const float inv = 1.0f / o2[0];
   const int qi = q0 + l31;
   if (qi < S) {
     f16* op = out + ((int64_t)frame * S + qi) * ldo + head * 64 + 4 * half;
@@ -212,17 +277,24 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
 
 extern "C" int gcd_attn_spatial_f16(const void* qkv, int64_t ld, const void* vt, int S_pad,
                                     void* out, int64_t ldo, int frames, int S, int heads,
-                                    void* stream) {
+                                    int q_prescaled, void* stream) {
   GCD_CHECK_ARG(qkv && vt && out, "gcd_attn_spatial_f16: null pointer");
   GCD_CHECK_ARG(frames > 0 && S > 0 && heads > 0, "gcd_attn_spatial_f16: empty problem");
   GCD_CHECK_ARG(S_pad % 64 == 0 && S_pad >= S, "gcd_attn_spatial_f16: S_pad=%d for S=%d", S_pad, S);
   GCD_CHECK_ARG(ld % 8 == 0 && ld >= 3 * heads * 64 && ldo % 4 == 0 && ldo >= heads * 64,
                 "gcd_attn_spatial_f16: ld=%lld ldo=%lld", (long long)ld, (long long)ldo);
-  GCD_CHECK_ARG(frames <= 65535 && heads <= 65535, "gcd_attn_spatial_f16: grid too large");
-  const float c = 0.125f * LOG2E_F;  // head dim 64 -> scale 1/8
-  hipLaunchKernelGGL(attn_spatial_kernel, dim3((S + 127) / 128, heads, frames), dim3(256), 0,
-                     (hipStream_t)stream, (const f16*)qkv, ld, (const f16*)vt, S_pad, (f16*)out, ldo,
-                     S, heads, c);
+  const int nqb = (S + 127) / 128;
+  const int64_t nblk = (int64_t)nqb * heads * frames;
+  GCD_CHECK_ARG(nblk < (1ll << 31), "gcd_attn_spatial_f16: grid too large");
+  const float c = 0.125f * LOG2E_F;  // head dim 64 -> scale 1/8, in exp2 units
+  const dim3 grid((unsigned)nblk), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (q_prescaled)
+    hipLaunchKernelGGL(attn_spatial_kernel<true>, grid, block, 0, st, (const f16*)qkv, ld,
+                       (const f16*)vt, S_pad, (f16*)out, ldo, S, heads, nqb, c);
+  else
+    hipLaunchKernelGGL(attn_spatial_kernel<false>, grid, block, 0, st, (const f16*)qkv, ld,
+                       (const f16*)vt, S_pad, (f16*)out, ldo, S, heads, nqb, c);
   GCD_CHECK_LAUNCH();
   return 0;
 }

@@ -62,19 +62,25 @@ __device__ __forceinline__ float gelu_f(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-// GELU (erf form) with erfc from Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, far below the
-// fp16 rounding of every consumer): 2 transcendentals + ~12 VALU instead of libm's erff.
-//   gelu(g) = g * Phi(g),  Phi(g) = 1 - erfc(|g|/sqrt2)/2 for g >= 0, erfc(|g|/sqrt2)/2 otherwise
+// GELU (erf form): g * Phi(g) with the normal CDF as an odd minimax polynomial on the clamped
+// argument, Phi(x) = 1/2 + xc * P(u), xc = clamp(x, -4.5, 4.5), u = 2 xc^2 / 4.5^2 - 1, degree-9 P
+// (Lawson fit, |Phi error| <= 7.1e-6 including the clamp, see tools/fit_gelu.py).  14 full-rate VALU
+// instructions and no transcendental: the GEGLU epilogues are instruction-issue bound, libm's erff
+// (~40 instructions) and even a 2-transcendental Abramowitz-Stegun form cost 2-3x as much.
 __device__ __forceinline__ float gelu_fast(float g) {
-  const float x = fabsf(g) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  poly *= t;
-  const float h = 0.5f * poly * __builtin_amdgcn_exp2f(-x * x * 1.4426950408889634f);
-  return g * (g >= 0.f ? 1.0f - h : h);
+  const float xc = __builtin_amdgcn_fmed3f(g, -4.5f, 4.5f);
+  const float u = fmaf(xc * xc, 2.0f / 20.25f, -1.0f);
+  float p = -1.928577467e-03f;
+  p = fmaf(p, u, 4.953202455e-03f);
+  p = fmaf(p, u, -6.067269522e-03f);
+  p = fmaf(p, u, 9.667675117e-03f);
+  p = fmaf(p, u, -1.849089463e-02f);
+  p = fmaf(p, u, 2.885118603e-02f);
+  p = fmaf(p, u, -4.023398011e-02f);
+  p = fmaf(p, u, 5.463833202e-02f);
+  p = fmaf(p, u, -7.718616753e-02f);
+  p = fmaf(p, u, 1.569060299e-01f);
+  return g * fmaf(xc, p, 0.5f);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -59,12 +59,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
   const int l31 = lane & 31, hh = lane >> 5;
 
   // ---- XCD-aware, panel-sharing tile assignment (bijective for any grid) ----
-  int tile_m, tile_n;
+  // Each XCD owns a contiguous range of the linear tile order.  One tile per workgroup, or (VAR bit
+  // 2048, persistent) 32 workgroups per XCD that walk their XCD's range with stride 32.
+  constexpr bool PERSIST = (VAR & 2048) != 0;
+  int L, L_end, L_step;
   {
-    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int nblk = PERSIST ? p.tiles_m * p.tiles_n : (int)gridDim.x, bid = blockIdx.x;
     const int q = nblk >> 3, r = nblk & 7;
     const int xcd = bid & 7, idx = bid >> 3;
-    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    L = start + idx;
+    L_end = PERSIST ? start + q + (xcd < r ? 1 : 0) : L + 1;
+    L_step = PERSIST ? (int)(gridDim.x >> 3) : 1;
+  }
+  for (; L < L_end; L += L_step) {
+  int tile_m, tile_n;
+  {
     const int per_group = PP_GROUP_M * p.tiles_n;
     const int gi = L / per_group;
     const int rem = L - gi * per_group;
@@ -304,7 +314,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
 
   // ---- epilogue (gemm_common.h): LDS-transposed, 128-byte-row global accesses.  Every wave is
   //      past its last fragment read of the ring (see the barrier structure above). ----
-  gcd_epilogue_64x160<(VAR >> 6)>(p, acc, m0 + 64 * wm, n0 + 160 * wn, lane, smem + wave * GCD_EPI_STAGE_BYTES);
+  gcd_epilogue_64x160<((VAR >> 6) & 31)>(p, acc, m0 + 64 * wm, n0 + 160 * wn, lane, smem + wave * GCD_EPI_STAGE_BYTES);
+  if (PERSIST) __syncthreads();   // epilogue LDS staging vs the next tile's prologue DMA
+  }   // tile loop
 }
 
 template <int MODE, int VAR = 0>
@@ -319,8 +331,9 @@ int launch_pp(const GemmK& k, hipStream_t s) {
   GemmK kk = k;
   kk.tiles_m = (k.M + PP_BM - 1) / PP_BM;
   kk.tiles_n = (k.N + PP_BN - 1) / PP_BN;
-  const int64_t nblk = (int64_t)kk.tiles_m * kk.tiles_n;
+  int64_t nblk = (int64_t)kk.tiles_m * kk.tiles_n;
   GCD_CHECK_ARG(nblk > 0 && nblk < (1ll << 31), "gcd_gemm_f16 (pp): bad grid %lld", (long long)nblk);
+  if ((VAR & 2048) && nblk > 256) nblk = 256;   // persistent: one workgroup per CU, 32 per XCD
   hipLaunchKernelGGL(fn, dim3((unsigned)nblk), dim3(512), PP_SMEM, s, kk);
   GCD_CHECK_LAUNCH();
   return 0;
@@ -354,12 +367,16 @@ int gcd_gemm_pp_launch(const GemmK& k, int mode, hipStream_t s) {
       default: break;
     }
   }
+  // More tiles than CUs: 256 persistent workgroups walk the tiles (saves the per-workgroup launch /
+  // teardown, 6-7 % on the K = 320 / 640 shapes); otherwise one workgroup per tile.
+  const int64_t tiles = (int64_t)((k.M + PP_BM - 1) / PP_BM) * ((k.N + PP_BN - 1) / PP_BN);
+  const bool persist = tiles > 256 && gcd_tune_get(GCD_TUNE_GEMM_IMPL) != 4;   // knob 4: never persistent
   switch (mode) {
     case GCD_GEMM_PLAIN:
-      return launch_pp<GCD_GEMM_PLAIN>(k, s);
+      return persist ? launch_pp<GCD_GEMM_PLAIN, 2048>(k, s) : launch_pp<GCD_GEMM_PLAIN>(k, s);
     case GCD_GEMM_CONV3X3:
-      return launch_pp<GCD_GEMM_CONV3X3>(k, s);
+      return persist ? launch_pp<GCD_GEMM_CONV3X3, 2048>(k, s) : launch_pp<GCD_GEMM_CONV3X3>(k, s);
     default:
-      return launch_pp<GCD_GEMM_TEMPORAL3>(k, s);
+      return persist ? launch_pp<GCD_GEMM_TEMPORAL3, 2048>(k, s) : launch_pp<GCD_GEMM_TEMPORAL3>(k, s);
   }
 }

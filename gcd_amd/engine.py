@@ -193,8 +193,9 @@ class UNetEngine:
             w1, b1 = packing.pack_geglu(ff.net[0].proj.weight, ff.net[0].proj.bias)
             return dict(w1=w1, b1=b1, w2=packing.pack_linear(ff.net[2].weight), b2=_f32(ff.net[2].bias))
 
-        def pack_attn(att):
-            return dict(wqkv=packing.pack_qkv(att.to_q.weight, att.to_k.weight, att.to_v.weight),
+        def pack_attn(att, q_scale=1.0):
+            return dict(wqkv=packing.pack_qkv(att.to_q.weight, att.to_k.weight, att.to_v.weight,
+                                              q_scale=q_scale),
                         wo=packing.pack_linear(att.to_out[0].weight), bo=_f32(att.to_out[0].bias))
 
         def pack_tr(tr: SpatialVideoTransformer):
@@ -204,7 +205,8 @@ class UNetEngine:
             d["wout"], d["bout"] = packing.pack_linear(tr.proj_out.weight), _f32(tr.proj_out.bias)
             d["blocks"] = []
             for sb, tb in zip(tr.transformer_blocks, tr.time_stack):
-                s = dict(ln1=ln(sb.norm1), attn=pack_attn(sb.attn1), ca=add_ca(sb.attn2, False),
+                s = dict(ln1=ln(sb.norm1), attn=pack_attn(sb.attn1, ops.ATTN_Q_SCALE_LOG2),
+                         ca=add_ca(sb.attn2, False),
                          ln3=ln(sb.norm3), ff=pack_ff(sb.ff))
                 t = dict(ln_in=ln(tb.norm_in), ff_in=pack_ff(tb.ff_in), ln1=ln(tb.norm1),
                          attn=pack_attn(tb.attn1), ca=add_ca(tb.attn2, True), ln3=ln(tb.norm3),
@@ -383,7 +385,7 @@ class UNetEngine:
             vt = ws.alloc((N * heads * 64 * S_pad,), torch.float16)
             ops.attn_transpose_v(qkv, N, HW, heads, vt, S_pad)
             ao = ws.alloc((M, Cc), torch.float16)
-            ops.attn_spatial(qkv, vt, S_pad, ao, N, HW, heads)
+            ops.attn_spatial(qkv, vt, S_pad, ao, N, HW, heads, q_prescaled=True)
             ws.release(qkv, vt)
             # x = attn1 + x ; x = attn2 + x  (attn2 == per-frame vector, one key)
             ops.gemm(ao, sb["attn"]["wo"], xs, M=M, bias=sb["attn"]["bo"], r1=xs,

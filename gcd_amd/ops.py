@@ -198,12 +198,17 @@ def attn_transpose_v(qkv16, frames: int, S: int, heads: int, vt16, S_pad: int):
     return vt16
 
 
-def attn_spatial(qkv16, vt16, S_pad: int, out16, frames: int, S: int, heads: int):
+# softmax scale of the 64-wide heads in exp2 units; packing.pack_qkv folds it into W_q
+ATTN_Q_SCALE_LOG2 = 0.125 * 1.4426950408889634
+
+
+def attn_spatial(qkv16, vt16, S_pad: int, out16, frames: int, S: int, heads: int,
+                 q_prescaled: bool = False):
     _need_gpu(qkv16, vt16, out16)
     with _Timed("attn_spatial", 4.0 * frames * heads * S * S * 64, S=S, frames=frames, heads=heads):
         check(_lib.load().gcd_attn_spatial_f16(qkv16.data_ptr(), _ld(qkv16), vt16.data_ptr(), S_pad,
                                                out16.data_ptr(), _ld(out16), frames, S, heads,
-                                               _stream()), "gcd_attn_spatial_f16")
+                                               int(q_prescaled), _stream()), "gcd_attn_spatial_f16")
     return out16
 
 

@@ -42,9 +42,17 @@ def pack_conv_t3(w: torch.Tensor) -> torch.Tensor:
         torch.float16).contiguous()
 
 
-def pack_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor) -> torch.Tensor:
-    """to_q / to_k / to_v weights [C, C] -> one fp16 [3C, C] so q|k|v come out of a single GEMM."""
-    return torch.cat([wq.detach(), wk.detach(), wv.detach()], 0).to(torch.float16).contiguous()
+def pack_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, q_scale: float = 1.0) -> torch.Tensor:
+    """to_q / to_k / to_v weights [C, C] -> one fp16 [3C, C] so q|k|v come out of a single GEMM.
+
+    q_scale (spatial attention: log2(e)/sqrt(d)) is multiplied into W_q in fp32 BEFORE the single
+    fp16 rounding, so the attention kernel receives scores that are already exp2 arguments at no
+    loss of precision (gcd_attn_spatial_f16, q_prescaled = 1)."""
+    wq32 = wq.detach().to(torch.float32)
+    if q_scale != 1.0:
+        wq32 = wq32 * q_scale
+    return torch.cat([wq32, wk.detach().to(torch.float32), wv.detach().to(torch.float32)], 0).to(
+        torch.float16).contiguous()
 
 
 def geglu_row_order(inner: int, device=None) -> torch.Tensor:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GCD_AMD_ABI_VERSION 1
+#define GCD_AMD_ABI_VERSION 2
 
 /* ---- library ------------------------------------------------------------------------------ */
 int gcd_abi_version(void);
@@ -40,7 +40,8 @@ int gcd_device_info(int device, char* name, int cap, int* num_cus, size_t* hbm_b
 /* Kernel-selection knobs (diagnostics / A-B benchmarking; results are identical up to fp32
  * accumulation order whichever kernel runs).  Initial values come from the environment variables
  * GCD_GEMM_IMPL / GCD_ATTN_IMPL.
- *   GCD_TUNE_GEMM_IMPL: 0 = automatic, 1 = general 128-row kernel, 2 = 256x320 ping-pong kernel
+ *   GCD_TUNE_GEMM_IMPL: 0 = automatic, 1 = general 128-row kernel, 2 = 256x320 ping-pong kernel,
+ *                       4 = ping-pong kernel, never persistent; >= 32: ablation builds (gemm_pp.hip)
  *   GCD_TUNE_ATTN_IMPL: 0 = automatic, other values select spatial-attention kernel variants   */
 #define GCD_TUNE_GEMM_IMPL 0
 #define GCD_TUNE_ATTN_IMPL 1
@@ -132,14 +133,19 @@ int gcd_layernorm_f16(const float* x, int64_t ldx, int64_t M, int C, const float
                       void* stream);
 
 /* ---- attention ------------------------------------------------------------------------------ */
-/* vt[((f*heads+h)*64 + d) * S_pad + s] = qkv[(f*S+s)*ld + 2C + h*64 + d], zero padded to S_pad. */
+/* vt[((f*heads+h)*64 + d) * S_pad + p(s)] = qkv[(f*S+s)*ld + 2C + h*64 + d], zero padded to S_pad;
+ * p swaps the two middle quads of every group of 16 keys (0-3, 8-11, 4-7, 12-15), the order in
+ * which gcd_attn_spatial_f16's P V MFMA consumes them.  vt is private to that kernel.            */
 int gcd_attn_transpose_v(const void* qkv, int64_t ld, int frames, int S, int heads, void* vt,
                          int S_pad, void* stream);
 /* Spatial self-attention, head dim 64, softmax scale 1/8 (F.scaled_dot_product_attention at
  * attention.py:331-335).  qkv: fp16 [frames*S, 3C] (q | k | v, head-major columns), vt from
- * gcd_attn_transpose_v, out: fp16 [frames*S, C].                                               */
+ * gcd_attn_transpose_v, out: fp16 [frames*S, C].
+ * q_prescaled != 0: the q columns already carry the factor log2(e)/8 (folded into W_q in fp32 when
+ * the projection weights are packed — one fp16 rounding, same as without it), so scores are exp2
+ * arguments and the kernel spends no instruction on scaling.  0: plain q, the kernel scales.      */
 int gcd_attn_spatial_f16(const void* qkv, int64_t ld, const void* vt, int S_pad, void* out,
-                         int64_t ldo, int frames, int S, int heads, void* stream);
+                         int64_t ldo, int frames, int S, int heads, int q_prescaled, void* stream);
 /* Temporal self-attention over T <= 16 frames per (clip, pixel, head)
  * (video_attention.py:114,126-129 -> attention.py:331-335).  Rows are ((b*T + t)*HW + s).       */
 int gcd_attn_temporal_f16(const void* qkv, int64_t ld, void* out, int64_t ldo, int clips, int T,

@@ -275,9 +275,55 @@ def test_attention_spatial(gpu, frames, S, heads):
     torch.cuda.synchronize()
     vt_ref = torch.zeros(frames, heads, 64, S_pad)
     vt_ref[..., :S] = v.permute(0, 1, 3, 2)
-    assert torch.equal(vt.cpu().float().reshape(frames, heads, 64, S_pad), vt_ref), "V^T mismatch"
+    # gcd_attn_transpose_v stores every 16-key group as keys 0-3, 8-11, 4-7, 12-15
+    perm = torch.arange(S_pad).reshape(-1, 4, 4)[:, [0, 2, 1, 3]].reshape(-1)
+    assert torch.equal(vt.cpu().float().reshape(frames, heads, 64, S_pad), vt_ref[..., perm]), "V^T mismatch"
     e = rel_l2(out.float(), ref)
     assert e < 1.5e-3, f"spatial attention S={S}: rel-L2 {e:.3e}"
+    # q_prescaled = 1: q carries log2(e)/8 (what packing.pack_qkv folds into W_q); reference on the
+    # fp16-rounded scaled q so that both paths see the same operand
+    qs = _h(qkv[:, :C] * ops.ATTN_Q_SCALE_LOG2)
+    q2 = (qs / ops.ATTN_Q_SCALE_LOG2).reshape(frames, S, heads, 64).permute(0, 2, 1, 3)
+    ref2 = F.scaled_dot_product_attention(q2.double(), k.double(), v.double())
+    ref2 = ref2.permute(0, 2, 1, 3).reshape(frames * S, C).float()
+    qg2 = torch.cat([qs, qkv[:, C:]], 1).half().to(gpu)
+    out2 = torch.empty_like(out)
+    ops.attn_spatial(qg2, vt, S_pad, out2, frames, S, heads, q_prescaled=True)
+    torch.cuda.synchronize()
+    e = rel_l2(out2.float(), ref2)
+    assert e < 1.5e-3, f"spatial attention (prescaled q) S={S}: rel-L2 {e:.3e}"
+
+
+def test_attention_spatial_reference_shift(gpu):
+    """Scores that drift up and down by far more than the lazy-rescale threshold, a first tile whose
+    scores are hugely negative, and a late outlier key: every branch of the reference-max logic."""
+    from gcd_amd import ops
+    g = _gen(12)
+    frames, S, heads = 1, 640, 1
+    C = 64
+    q = torch.randn(S, 64, generator=g)
+    k = torch.randn(S, 64, generator=g)
+    v = torch.randn(S, 64, generator=g)
+    u = torch.randn(64, generator=g)
+    u /= u.norm()
+    q = q + 30.0 * u                               # every query has a big component along u
+    ramp = torch.linspace(-4.0, 4.0, S)            # keys drift along u: scores sweep ~[-120, 120]/8
+    k = k + ramp[:, None] * u
+    k[500] += 3.0 * u                               # late outlier
+    qkv = _h(torch.cat([q, k, v], 1))
+    qq, kk, vv = [t.reshape(1, S, 1, 64).permute(0, 2, 1, 3) for t in qkv.split(C, dim=1)]
+    ref = F.scaled_dot_product_attention(qq.double(), kk.double(), vv.double())
+    ref = ref.permute(0, 2, 1, 3).reshape(S, C).float()
+    S_pad = S
+    qg = qkv.half().to(gpu)
+    vt = torch.empty(64 * S_pad, dtype=torch.float16, device=gpu)
+    ops.attn_transpose_v(qg, frames, S, heads, vt, S_pad)
+    out = torch.empty(S, C, dtype=torch.float16, device=gpu)
+    ops.attn_spatial(qg, vt, S_pad, out, frames, S, heads)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    e = rel_l2(out.float(), ref)
+    assert e < 2e-3, f"reference-shift attention: rel-L2 {e:.3e}"
 
 
 @pytest.mark.parametrize("clips,T,HW,heads", [(2, 14, 10, 3), (1, 4, 33, 1), (2, 16, 7, 5),
