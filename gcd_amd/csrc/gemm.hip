@@ -259,6 +259,11 @@ static int dispatch_tile(const GemmK& k, hipStream_t s) {
     const int pad128 = (k.N + 127) / 128 * 128, pad160 = (k.N + 159) / 160 * 160;
     use160 = pad160 <= pad128;
   }
+  // few 128-row tiles (the 9 x 16 bottleneck level: M = 4032): 64-row tiles double the number of
+  // workgroups so that two are resident per CU
+  const int64_t tiles128 = (int64_t)((k.M + 127) / 128) * ((k.N + 159) / 160);
+  const int impl = gcd_tune_get(GCD_TUNE_GEMM_IMPL);
+  if (use160 && ((tiles128 <= 320 && impl != 5) || impl == 6)) return launch_gemm<64, 160, 32, 80, MODE>(k, s);
   if (use160) return launch_gemm<128, 160, 64, 80, MODE>(k, s);
   return launch_gemm<128, 128, 64, 64, MODE>(k, s);
 }
@@ -268,7 +273,7 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
   GCD_CHECK_ARG(d->A && d->W && d->out, "gcd_gemm_f16: null operand");
   GCD_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "gcd_gemm_f16: empty problem M=%d N=%d K=%d",
                 d->M, d->N, d->K);
-  GCD_CHECK_ARG(d->K % 64 == 0, "gcd_gemm_f16: K=%d must be a multiple of 64", d->K);
+  GCD_CHECK_ARG(d->K % 32 == 0, "gcd_gemm_f16: K=%d must be a multiple of 32", d->K);
   GCD_CHECK_ARG(d->N % 16 == 0, "gcd_gemm_f16: N=%d must be a multiple of 16", d->N);
   GCD_CHECK_ARG(d->lda % 8 == 0, "gcd_gemm_f16: lda=%lld must be a multiple of 8 (16-B rows)",
                 (long long)d->lda);
@@ -331,10 +336,16 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
   // its (large) tiles, the general 128-row kernel otherwise.  GCD_TUNE_GEMM_IMPL overrides.
   const int impl = gcd_tune_get(GCD_TUNE_GEMM_IMPL);
   bool use_pp = false;
-  if (impl != 1 && gcd_gemm_pp_supported(k, d->mode)) {
+  if (impl != 1 && impl != 5 && impl != 6 && gcd_gemm_pp_supported(k, d->mode)) {
     const int64_t tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 319) / 320);
     use_pp = impl >= 2 || (impl == 0 && tiles >= 192 && d->N >= 160);
+    // K (or the channels per tap) a multiple of 32 but not of 64: only the ping-pong kernel's 32-deep
+    // sub-tiles can walk it
+    if (d->K % 64 != 0 || (d->mode != GCD_GEMM_PLAIN && d->Cin % 64 != 0)) use_pp = true;
   }
+  GCD_CHECK_ARG(use_pp || (d->K % 64 == 0 && (d->mode == GCD_GEMM_PLAIN || d->Cin % 64 == 0)),
+                "gcd_gemm_f16: K=%d (Cin=%d) needs the ping-pong kernel, which the shape or "
+                "GCD_TUNE_GEMM_IMPL=%d rules out", d->K, d->Cin, impl);
 
   switch (d->mode) {
     case GCD_GEMM_PLAIN:
@@ -342,8 +353,8 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
       return dispatch_tile<GCD_GEMM_PLAIN>(k, s);
     case GCD_GEMM_CONV3X3: {
       GCD_CHECK_ARG(d->zero_page, "gcd_gemm_f16: conv mode needs a zero page");
-      GCD_CHECK_ARG(d->Cin > 0 && d->Cin % 64 == 0 && d->K == 9 * d->Cin,
-                    "gcd_gemm_f16: conv3x3 needs Cin %% 64 == 0 and K == 9*Cin (Cin=%d K=%d)",
+      GCD_CHECK_ARG(d->Cin > 0 && d->Cin % 32 == 0 && d->K == 9 * d->Cin,
+                    "gcd_gemm_f16: conv3x3 needs Cin %% 32 == 0 and K == 9*Cin (Cin=%d K=%d)",
                     d->Cin, d->K);
       GCD_CHECK_ARG(d->stride == 1 || d->stride == 2, "gcd_gemm_f16: stride %d", d->stride);
       GCD_CHECK_ARG(d->Ho > 0 && d->Wo > 0 && d->M % (d->Ho * d->Wo) == 0,
@@ -360,8 +371,8 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
     }
     case GCD_GEMM_TEMPORAL3: {
       GCD_CHECK_ARG(d->zero_page, "gcd_gemm_f16: temporal mode needs a zero page");
-      GCD_CHECK_ARG(d->Cin > 0 && d->Cin % 64 == 0 && d->K == 3 * d->Cin,
-                    "gcd_gemm_f16: temporal3 needs Cin %% 64 == 0 and K == 3*Cin");
+      GCD_CHECK_ARG(d->Cin > 0 && d->Cin % 32 == 0 && d->K == 3 * d->Cin,
+                    "gcd_gemm_f16: temporal3 needs Cin %% 32 == 0 and K == 3*Cin");
       GCD_CHECK_ARG(d->T > 0 && d->HW > 0 && d->M % (d->T * d->HW) == 0,
                     "gcd_gemm_f16: M=%d is not clips*T*HW (T=%d HW=%d)", d->M, d->T, d->HW);
       if (use_pp) return gcd_gemm_pp_launch(k, d->mode, s);

@@ -57,6 +57,15 @@ class _Timed:
         return False
 
 
+TUNE_GEMM_IMPL, TUNE_ATTN_IMPL = 0, 1
+
+
+def tune_set(knob: int, value: int) -> None:
+    """Kernel-selection knob of libgcd_amd (gcd_tune_set): used by the tests to force every GEMM
+    kernel over the same cases, and by the A/B tools."""
+    check(_lib.load().gcd_tune_set(knob, value), "gcd_tune_set")
+
+
 def _need_gpu(*ts) -> None:
     for t in ts:
         if t is not None and not t.is_cuda:

@@ -41,7 +41,8 @@ int gcd_device_info(int device, char* name, int cap, int* num_cus, size_t* hbm_b
  * accumulation order whichever kernel runs).  Initial values come from the environment variables
  * GCD_GEMM_IMPL / GCD_ATTN_IMPL.
  *   GCD_TUNE_GEMM_IMPL: 0 = automatic, 1 = general 128-row kernel, 2 = 256x320 ping-pong kernel,
- *                       4 = ping-pong kernel, never persistent; >= 32: ablation builds (gemm_pp.hip)
+ *                       4 = ping-pong kernel, never persistent; 5 / 6 = general kernel, never / always
+ *                       64-row tiles; >= 32: ablation builds (gemm_pp.hip)
  *   GCD_TUNE_ATTN_IMPL: 0 = automatic, other values select spatial-attention kernel variants   */
 #define GCD_TUNE_GEMM_IMPL 0
 #define GCD_TUNE_ATTN_IMPL 1

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()                       # raises if the .so has not been built
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.gcd_abi_version() == _lib.ABI_VERSION == 1
+    assert lib.gcd_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_gemm_desc_layout_matches_header(tmp_path):
@@ -62,7 +62,7 @@ def test_ops_refuse_cpu_tensors_and_bad_args():
     d.A = d.W = d.out = 16
     d.M, d.N, d.K, d.lda, d.ldo = 10, 32, 100, 104, 32
     assert lib.gcd_gemm_f16(ctypes.byref(d), None) != 0
-    assert b"multiple of 64" in lib.gcd_last_error()
+    assert b"multiple of 32" in lib.gcd_last_error()
     assert lib.gcd_attn_temporal_f16(16, 192, 16, 64, 1, 17, 4, 1, None) != 0
     assert b"T=17" in lib.gcd_last_error()
     assert lib.gcd_groupnorm_stats(16, 48, 48, None, 0, 0, 10, 10, 1e-5, 16, 1, 16, None) != 0
@@ -255,3 +255,18 @@ def test_workspace_replays_identical_placement():
     ws.reset(("other", 2))                           # new signature: re-plan, may grow
     ws.alloc((1000, 64), torch.float32)
     assert ws.nbytes() > n
+
+
+def test_pack_qkv_folds_the_softmax_scale_in_fp32():
+    """pack_qkv(q_scale): W_q * scale is formed in fp32 and rounded to fp16 ONCE (not fp16(W_q) * scale
+    re-rounded), k / v rows are untouched."""
+    from gcd_amd import ops, packing
+    g = torch.Generator().manual_seed(3)
+    wq, wk, wv = (torch.randn(64, 64, generator=g) for _ in range(3))
+    s = ops.ATTN_Q_SCALE_LOG2
+    assert abs(s - math.log2(math.e) / 8) < 1e-12
+    p = packing.pack_qkv(wq, wk, wv, q_scale=s)
+    assert p.dtype == torch.float16 and p.shape == (192, 64)
+    assert torch.equal(p[:64], (wq * s).half())
+    assert torch.equal(p[64:], torch.cat([wk, wv]).half())
+    assert torch.equal(packing.pack_qkv(wq, wk, wv), torch.cat([wq, wk, wv]).half())

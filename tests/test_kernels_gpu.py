@@ -26,7 +26,69 @@ def _gen(seed):
     return torch.Generator().manual_seed(seed)
 
 
+@pytest.fixture(params=[0, 2, 6], ids=["auto", "pingpong", "tile64"], autouse=True)
+def gemm_impl(request):
+    """Every test of this module runs with the automatic GEMM kernel choice, with the 256x320
+    ping-pong kernel forced and with the general kernel's 64-row tiles forced."""
+    from gcd_amd import ops
+    ops.tune_set(ops.TUNE_GEMM_IMPL, request.param)
+    yield request.param
+    ops.tune_set(ops.TUNE_GEMM_IMPL, 0)
+
+
 # ------------------------------------------------------------------------------------------ GEMM
+def test_gemm_pingpong_k32_and_persistent(gpu, gemm_impl):
+    """Shapes only the ping-pong kernel takes: K = 96 (three 32-deep sub-tiles, not a multiple of the
+    general kernel's 64) and a 40 x 8 tile grid (> 256 tiles: the persistent tile loop), ragged in
+    M and N, with every epilogue input."""
+    from gcd_amd import ops
+    if gemm_impl == 6:
+        pytest.skip("general kernel needs K % 64 == 0")
+    g = _gen(21)
+    for (M, N, K) in [(700, 352, 96), (256 * 39 + 77, 320 * 7 + 64, 64)]:
+        a = _h(torch.randn(M, K, generator=g))
+        w = _h(torch.randn(N, K, generator=g) / math.sqrt(K))
+        bias = torch.randn(N, generator=g)
+        r1 = torch.randn(M, N, generator=g)
+        rows = 333
+        rv = torch.randn((M + rows - 1) // rows, N, generator=g)
+        ref = a @ w.t() + bias + rv.repeat_interleave(rows, 0)[:M] + r1
+        out = torch.empty(M, N, device=gpu)
+        ops.gemm(a.half().to(gpu), w.half().to(gpu), out, M=M, bias=bias.to(gpu), rowvec=rv.to(gpu),
+                 rows_per_vec=rows, r1=r1.to(gpu))
+        torch.cuda.synchronize()
+        e = rel_l2(out, ref)
+        assert e < TOL_F32, f"M={M} N={N} K={K}: rel-L2 {e:.3e}"
+        out16 = torch.empty(M, N, device=gpu, dtype=torch.float16)
+        ops.gemm(a.half().to(gpu), w.half().to(gpu), out16, M=M, out_kind=ops.OUT_F16)
+        torch.cuda.synchronize()
+        e = rel_l2(out16.float(), a @ w.t())
+        assert e < TOL_F16, f"f16 out M={M} N={N} K={K}: rel-L2 {e:.3e}"
+
+
+def test_conv3x3_pingpong_full_tiles(gpu, gemm_impl):
+    """A conv whose grid fills whole 256 x 320 tiles (what the automatic choice sends to the ping-pong
+    kernel): 320 -> 320 channels on 28 frames of 24 x 32, stride 1 / stride 2 / fused x2 upsample."""
+    from gcd_amd import ops, packing
+    g = _gen(22)
+    frames, Cin, Cout = 28, 320, 320
+    for (H, W, stride, up) in [(24, 32, 1, 0), (24, 32, 2, 0), (12, 16, 1, 1)]:
+        x = _h(torch.randn(frames, Cin, H, W, generator=g))
+        w = _h(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+        b = torch.randn(Cout, generator=g)
+        xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+        ref = F.conv2d(xin, w, b, stride=stride, padding=1)
+        Ho, Wo = ref.shape[-2:]
+        ref_tok = ref.permute(0, 2, 3, 1).reshape(frames * Ho * Wo, Cout)
+        a = x.permute(0, 2, 3, 1).reshape(frames * H * W, Cin).half().to(gpu)
+        out = torch.empty(frames * Ho * Wo, Cout, device=gpu)
+        ops.gemm(a, packing.pack_conv3x3(w).to(gpu), out, M=frames * Ho * Wo, mode=ops.GEMM_CONV3X3,
+                 bias=b.to(gpu), conv=dict(Cin=Cin, Hi=H, Wi=W, Ho=Ho, Wo=Wo, stride=stride, upsample=up))
+        torch.cuda.synchronize()
+        e = rel_l2(out, ref_tok)
+        assert e < TOL_F32, f"conv3x3 {H}x{W} s{stride} up{up}: rel-L2 {e:.3e}"
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (128, 256, 64), (1000, 64, 640),
                                    (257, 960, 128), (4032, 1280, 1280), (112, 48, 192)])
 def test_gemm_plain_bias_residual(gpu, M, N, K):
@@ -346,7 +408,7 @@ def test_attention_temporal(gpu, clips, T, HW, heads):
 
 # ----------------------------------------------------------------------------------- small pieces
 @pytest.mark.parametrize("M,N,K", [(28, 1280, 320), (28, 1280, 1280), (14, 320, 1280), (2, 64, 1024),
-                                   (28, 100, 768), (28, 1280, 128)])
+                                   (28, 100, 768), (28, 1280, 128), (5, 33, 20), (16, 48, 260)])
 def test_linear_smallm(gpu, M, N, K):
     from gcd_amd import ops
     g = _gen(12)
