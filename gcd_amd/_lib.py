@@ -36,6 +36,10 @@ class GemmDesc(C.Structure):
         ("s_acc", C.c_float), ("s_r1", C.c_float), ("s_r2", C.c_float),
         ("frame_alpha", C.c_void_p), ("rows_per_alpha", C.c_int32), ("r1_blend", C.c_int32),
         ("out_kind", C.c_int32), ("zero_page", C.c_void_p),
+        ("ln_out16", C.c_void_p), ("ld_ln_out", C.c_int64), ("ln_gamma", C.c_void_p),
+        ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("ln_rows_per_vec", C.c_int32),
+        ("ln_addvec", C.c_void_p), ("ld_ln_addvec", C.c_int64), ("ln_sum_out", C.c_void_p),
+        ("ld_ln_sum", C.c_int64),
     ]
 
 
@@ -48,6 +52,7 @@ SIGNATURES = {
     "gcd_device_info": (_i, [_i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(C.c_size_t)]),
     "gcd_tune_set": (_i, [_i, _i]),
     "gcd_gemm_f16": (_i, [C.POINTER(GemmDesc), _vp]),
+    "gcd_gemm_ln_fusable": (_i, [_i, _i, _i, _i]),
     "gcd_linear_smallm_f32": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "gcd_groupnorm_stats": (_i, [_vp, _i64, _i, _vp, _i64, _i, _i64, _i64, _f, _vp, _i, _vp, _vp]),
     "gcd_groupnorm_apply": (_i, [_vp, _i64, _i, _vp, _i64, _i, _i64, _i64, _vp, _vp, _vp, _i, _vp,

@@ -330,6 +330,16 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
   k.out_kind = d->out_kind;
   k.zero = (const f16*)d->zero_page;
   k.tiles_m = k.tiles_n = 0;
+  k.ln_out = (f16*)d->ln_out16;
+  k.ld_ln_out = d->ld_ln_out;
+  k.ln_gamma = d->ln_gamma;
+  k.ln_beta = d->ln_beta;
+  k.ln_eps = d->ln_eps;
+  k.ln_rows_per_vec = d->ln_rows_per_vec;
+  k.ln_addvec = d->ln_addvec;
+  k.ld_ln_addvec = d->ld_ln_addvec;
+  k.ln_sum_out = d->ln_sum_out;
+  k.ld_ln_sum = d->ld_ln_sum;
   hipStream_t s = (hipStream_t)stream;
 
   // kernel choice: the 256 x 320 ping-pong kernel whenever the grid fills most of the chip with
@@ -342,6 +352,16 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
     // K (or the channels per tap) a multiple of 32 but not of 64: only the ping-pong kernel's 32-deep
     // sub-tiles can walk it
     if (d->K % 64 != 0 || (d->mode != GCD_GEMM_PLAIN && d->Cin % 64 != 0)) use_pp = true;
+  }
+  if (d->ln_out16) {
+    GCD_CHECK_ARG(use_pp && d->N == 320 && d->out_kind == GCD_OUT_F32 && d->ln_gamma && d->ln_beta &&
+                      d->ld_ln_out % 4 == 0 && ((uintptr_t)d->ln_out16 & 7) == 0,
+                  "gcd_gemm_f16: fused LayerNorm needs N == 320, fp32 out, gamma / beta and a shape "
+                  "the ping-pong kernel takes (M=%d N=%d; see gcd_gemm_ln_fusable)", d->M, d->N);
+    if (d->ln_addvec)
+      GCD_CHECK_ARG(d->ln_rows_per_vec > 0 && d->ld_ln_addvec % 4 == 0 &&
+                        (!d->ln_sum_out || d->ld_ln_sum % 4 == 0),
+                    "gcd_gemm_f16: bad fused-LayerNorm addvec geometry");
   }
   GCD_CHECK_ARG(use_pp || (d->K % 64 == 0 && (d->mode == GCD_GEMM_PLAIN || d->Cin % 64 == 0)),
                 "gcd_gemm_f16: K=%d (Cin=%d) needs the ping-pong kernel, which the shape or "
@@ -382,4 +402,13 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
       gcd_set_error("gcd_gemm_f16: unknown mode %d", d->mode);
       return 2;
   }
+}
+
+extern "C" int gcd_gemm_ln_fusable(int M, int N, int K, int mode) {
+  if (N != 320 || K <= 0 || K % 32 != 0 || M <= 0) return 0;
+  const int impl = gcd_tune_get(GCD_TUNE_GEMM_IMPL);
+  if (impl == 1 || impl == 5 || impl == 6) return 0;
+  const int64_t tiles = (int64_t)((M + 255) / 256);
+  (void)mode;
+  return (impl >= 2 || tiles >= 192) ? 1 : 0;
 }

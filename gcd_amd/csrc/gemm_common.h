@@ -25,6 +25,17 @@ struct GemmK {
   int out_kind;
   const f16* zero;
   int tiles_m, tiles_n;
+  // fused LayerNorm of the output rows (gemm_pp.hip, N == 320)
+  f16* ln_out;
+  int64_t ld_ln_out;
+  const float* ln_gamma;
+  const float* ln_beta;
+  float ln_eps;
+  int ln_rows_per_vec;
+  const float* ln_addvec;
+  int64_t ld_ln_addvec;
+  float* ln_sum_out;
+  int64_t ld_ln_sum;
 };
 
 // gemm_pp.hip: the 256 x 320 ping-pong kernel.
@@ -55,6 +66,101 @@ int gcd_tune_get(int knob);
 // and GEGLU outputs are written straight from the accumulator layout.
 // EV: experiment switches for tools/gemm_bench (0 = product): 1 skip residual loads, 2 skip stores,
 // 4 nontemporal stores, 8 force the direct path, 16 force the transposed path
+// Fused LayerNorm (p.ln_out != nullptr, N == 320 == the tile width, fp32 out): the two waves that
+// share a 64-token row block (wn = 0 / 1, 160 channels each) exchange per-row sum and sum of squares
+// through `red` (LDS, >= 4 KB, workgroup-shared; ONE __syncthreads, so every thread of the workgroup
+// must call this), then each normalises its own 160 channels from the registers that still hold the
+// fp32 row it just stored.  Single-pass variance in fp32 over 320 values (error ~1e-6 * E[x^2]).
+__device__ __forceinline__ void gcd_epilogue_64x160_ln(const GemmK& p, f32x16 (&acc)[5][2],
+                                                       int m_base, int n_base, int lane, int wm,
+                                                       int wn, float* red) {
+  const int l31 = lane & 31, hh = lane >> 5;
+  float rs[2] = {0.f, 0.f}, rq[2] = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m_base + 32 * j + l31;
+    const bool mok = m < p.M;
+    const int mc = mok ? m : p.M - 1;
+    float sa = p.s_acc, sr1 = p.s_r1, sr2 = p.s_r2;
+    if (p.frame_alpha) {
+      const float al = p.frame_alpha[mc / p.rows_per_alpha];
+      sa = 1.0f - al;
+      sr2 = al;
+      if (p.r1_blend) sr1 *= 1.0f - al;
+    }
+    const float* rv = p.rowvec ? p.rowvec + (int64_t)(mc / p.rows_per_vec) * p.ld_rowvec : nullptr;
+    const float* av = p.ln_addvec ? p.ln_addvec + (int64_t)(mc / p.ln_rows_per_vec) * p.ld_ln_addvec
+                                  : nullptr;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      __builtin_amdgcn_sched_barrier(0);   // keep the loads of one column block together (registers)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n_base + 32 * i + 8 * g + 4 * hh;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+        if (p.bias) v += *(const f32x4*)(p.bias + n);
+        if (rv) v += *(const f32x4*)(rv + n);
+        v *= sa;
+        if (p.R1) v += sr1 * *(const f32x4*)(p.R1 + (int64_t)mc * p.ldr1 + n);
+        if (p.R2) v += sr2 * *(const f32x4*)(p.R2 + (int64_t)mc * p.ldr2 + n);
+        if (mok) *(f32x4*)((float*)p.out + (int64_t)m * p.ldo + n) = v;
+        if (av) {
+          v += *(const f32x4*)(av + n);
+          if (p.ln_sum_out && mok) *(f32x4*)(p.ln_sum_out + (int64_t)m * p.ld_ln_sum + n) = v;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[i][j][4 * g + e] = v[e];
+          rs[j] += v[e];
+          rq[j] = fmaf(v[e], v[e], rq[j]);
+        }
+      }
+    }
+  }
+  // lane ^ 32 holds the other half of this wave's 160 channels of the same row
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(rs[j]), __float_as_uint(rs[j]), false, false);
+    rs[j] = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(rq[j]), __float_as_uint(rq[j]), false, false);
+    rq[j] = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+    if (hh == 0) {
+      float* dst = red + ((wn * 4 + wm) * 64 + 32 * j + l31) * 2;
+      dst[0] = rs[j];
+      dst[1] = rq[j];
+    }
+  }
+  __syncthreads();
+  float mean[2], rstd[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float* src = red + (((1 - wn) * 4 + wm) * 64 + 32 * j + l31) * 2;
+    const float s = rs[j] + src[0], q = rq[j] + src[1];
+    mean[j] = s * (1.0f / 320.0f);
+    const float var = fmaxf(q * (1.0f / 320.0f) - mean[j] * mean[j], 0.f);
+    rstd[j] = rsqrtf(var + p.ln_eps);
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      __builtin_amdgcn_sched_barrier(0);
+      const int n = n_base + 32 * i + 8 * g + 4 * hh;
+      const f32x4 ga = *(const f32x4*)(p.ln_gamma + n), be = *(const f32x4*)(p.ln_beta + n);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int m = m_base + 32 * j + l31;
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = (f16)fmaf((acc[i][j][4 * g + e] - mean[j]) * rstd[j], ga[e], be[e]);
+        if (m < p.M) *(f16x4*)(p.ln_out + (int64_t)m * p.ld_ln_out + n) = o;
+      }
+    }
+}
+
 template <int EV = 0>
 __device__ __forceinline__ void gcd_epilogue_64x160(const GemmK& p, f32x16 (&acc)[5][2], int m_base,
                                                     int n_base, int lane, char* stage) {

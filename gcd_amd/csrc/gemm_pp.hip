@@ -314,8 +314,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
 
   // ---- epilogue (gemm_common.h): LDS-transposed, 128-byte-row global accesses.  Every wave is
   //      past its last fragment read of the ring (see the barrier structure above). ----
-  gcd_epilogue_64x160<((VAR >> 6) & 31)>(p, acc, m0 + 64 * wm, n0 + 160 * wn, lane, smem + wave * GCD_EPI_STAGE_BYTES);
-  if (PERSIST) __syncthreads();   // epilogue LDS staging vs the next tile's prologue DMA
+  if constexpr ((VAR & 8192) != 0)   // own instantiation: fused LayerNorm of the output rows (N == 320)
+    gcd_epilogue_64x160_ln(p, acc, m0 + 64 * wm, n0 + 160 * wn, lane, wm, wn, (float*)smem);
+  else
+    gcd_epilogue_64x160<((VAR >> 6) & 31)>(p, acc, m0 + 64 * wm, n0 + 160 * wn, lane,
+                                           smem + wave * GCD_EPI_STAGE_BYTES);
+  if (PERSIST) __syncthreads();   // epilogue LDS use vs the next tile's prologue DMA
   }   // tile loop
 }
 
@@ -371,6 +375,13 @@ int gcd_gemm_pp_launch(const GemmK& k, int mode, hipStream_t s) {
   // teardown, 6-7 % on the K = 320 / 640 shapes); otherwise one workgroup per tile.
   const int64_t tiles = (int64_t)((k.M + PP_BM - 1) / PP_BM) * ((k.N + PP_BN - 1) / PP_BN);
   const bool persist = tiles > 256 && gcd_tune_get(GCD_TUNE_GEMM_IMPL) != 4;   // knob 4: never persistent
+  if (k.ln_out) {   // validated by gcd_gemm_f16: PLAIN mode, N == 320
+    if (mode != GCD_GEMM_PLAIN) {
+      gcd_set_error("gcd_gemm_f16: fused LayerNorm is implemented for GCD_GEMM_PLAIN only");
+      return 2;
+    }
+    return persist ? launch_pp<GCD_GEMM_PLAIN, 2048 + 8192>(k, s) : launch_pp<GCD_GEMM_PLAIN, 8192>(k, s);
+  }
   switch (mode) {
     case GCD_GEMM_PLAIN:
       return persist ? launch_pp<GCD_GEMM_PLAIN, 2048>(k, s) : launch_pp<GCD_GEMM_PLAIN>(k, s);

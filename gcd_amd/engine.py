@@ -19,6 +19,7 @@ warm-up call every buffer address is stable and the whole forward can be replaye
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -111,6 +112,10 @@ class UNetEngine:
         self.ws: Optional[Workspace] = None
         self._graphs: Dict[tuple, dict] = {}
         self.use_graph = False
+        # LayerNorm in the epilogue of the N == 320 GEMMs.  Measured neutral on MI355X (7.288 vs 7.297
+        # steps/s in interleaved runs: the stand-alone LayerNorm already runs at 5.9 TB/s and the fused
+        # epilogue pays for it in VALU and 8-byte fp16 stores), so it is off unless GCD_FUSE_LN=1.
+        self.fuse_layernorm = os.environ.get("GCD_FUSE_LN", "0") == "1"
         self.taps: Optional[dict] = None   # debug: name -> NCHW fp32 clone of every block output
 
     # ------------------------------------------------------------------------------------------
@@ -371,14 +376,26 @@ class UNetEngine:
         ca = st["ca"]
         a16, _ = self._gn(x, None, HW, 1e-6, L["gn"], False, False)
         xs = ws.alloc((M, Cc), torch.float32)
-        ops.gemm(a16, L["win"], xs, M=M, bias=L["bin"])
+        # LayerNorm fused into the epilogue of the GEMM that writes its input (C == 320 rows fit one
+        # 256x320 tile of the ping-pong kernel); otherwise the stand-alone kernel.
+        fuse = self.fuse_layernorm and ops.gemm_ln_fusable(M, Cc, Cc)
+
+        def ln_req(affine, **extra):
+            if not fuse:
+                return None, None
+            y = ws.alloc((M, Cc), torch.float16)
+            return y, dict(gamma=affine[0], beta=affine[1], out16=y, **extra)
+
+        blocks = L["blocks"]
+        nxt, req = ln_req(blocks[0][0]["ln1"])
+        ops.gemm(a16, L["win"], xs, M=M, bias=L["bin"], ln=req)
         ws.release(a16)
         pos = self._pos_embed(L["pos"], N, T)
         S_pad = (HW + 63) // 64 * 64
         last = None
-        for bi, (sb, tb) in enumerate(L["blocks"]):
+        for bi, (sb, tb) in enumerate(blocks):
             # ---- spatial BasicTransformerBlock (attention.py:551-572) ----
-            a16 = self._ln(xs, sb["ln1"])
+            a16 = nxt if fuse else self._ln(xs, sb["ln1"])
             qkv = ws.alloc((M, 3 * Cc), torch.float16)
             ops.gemm(a16, sb["attn"]["wqkv"], qkv, M=M, out_kind=OUT_F16)
             ws.release(a16)
@@ -388,35 +405,40 @@ class UNetEngine:
             ops.attn_spatial(qkv, vt, S_pad, ao, N, HW, heads, q_prescaled=True)
             ws.release(qkv, vt)
             # x = attn1 + x ; x = attn2 + x  (attn2 == per-frame vector, one key)
+            nxt, req = ln_req(sb["ln3"])
             ops.gemm(ao, sb["attn"]["wo"], xs, M=M, bias=sb["attn"]["bo"], r1=xs,
-                     rowvec=ca[sb["ca"]], rows_per_vec=HW)
+                     rowvec=ca[sb["ca"]], rows_per_vec=HW, ln=req)
             ws.release(ao)
-            a16 = self._ln(xs, sb["ln3"])
-            self._ff(sb["ff"], a16, M, out=xs, r1=xs)
+            a16 = nxt if fuse else self._ln(xs, sb["ln3"])
             # ---- temporal VideoTransformerBlock (video_attention.py:109-140) on x + frame pos-emb ----
             xm = ws.alloc((M, Cc), torch.float32)
-            a16 = self._ln(xs, tb["ln_in"], addvec=pos, rows_per_vec=HW, sum_out=xm)
-            self._ff(tb["ff_in"], a16, M, out=xm, r1=xm)
-            a16 = self._ln(xm, tb["ln1"])
+            nxt, req = ln_req(tb["ln_in"], addvec=pos, rows_per_vec=HW, sum_out=xm)
+            self._ff(sb["ff"], a16, M, out=xs, r1=xs, ln=req)
+            a16 = nxt if fuse else self._ln(xs, tb["ln_in"], addvec=pos, rows_per_vec=HW, sum_out=xm)
+            nxt, req = ln_req(tb["ln1"])
+            self._ff(tb["ff_in"], a16, M, out=xm, r1=xm, ln=req)
+            a16 = nxt if fuse else self._ln(xm, tb["ln1"])
             qkv = ws.alloc((M, 3 * Cc), torch.float16)
             ops.gemm(a16, tb["attn"]["wqkv"], qkv, M=M, out_kind=OUT_F16)
             ws.release(a16)
             ao = ws.alloc((M, Cc), torch.float16)
             ops.attn_temporal(qkv, ao, N // T, T, HW, heads)
             ws.release(qkv)
+            nxt, req = ln_req(tb["ln3"])
             ops.gemm(ao, tb["attn"]["wo"], xm, M=M, bias=tb["attn"]["bo"], r1=xm,
-                     rowvec=ca[tb["ca"]], rows_per_vec=T * HW)
+                     rowvec=ca[tb["ca"]], rows_per_vec=T * HW, ln=req)
             ws.release(ao)
-            a16 = self._ln(xm, tb["ln3"])
+            a16 = nxt if fuse else self._ln(xm, tb["ln3"])
             # x = alpha*x + (1-alpha)*(ff(...) + x_mix)   (AlphaBlender, video_attention.py:289-293)
-            final = bi == len(L["blocks"]) - 1
+            final = bi == len(blocks) - 1
             if final:   # only proj_out reads the result: emit it as the fp16 GEMM operand directly
                 last = ws.alloc((M, Cc), torch.float16)
                 self._ff(tb["ff"], a16, M, out=last, out_kind=OUT_F16, r1=xm, r2=xs,
                          frame_alpha=st["alphas"][L["blend"]], rows_per_alpha=HW, r1_blend=True)
             else:
+                nxt, req = ln_req(blocks[bi + 1][0]["ln1"])
                 self._ff(tb["ff"], a16, M, out=xs, r1=xm, r2=xs,
-                         frame_alpha=st["alphas"][L["blend"]], rows_per_alpha=HW, r1_blend=True)
+                         frame_alpha=st["alphas"][L["blend"]], rows_per_alpha=HW, r1_blend=True, ln=req)
             ws.release(xm)
         ws.release(xs)
         ops.gemm(last, L["wout"], x, M=M, bias=L["bout"], r1=x)       # + x_in

@@ -100,7 +100,7 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mod
          out_kind: int = OUT_F32, bias=None, rowvec=None, rows_per_vec: int = 1, r1=None, r2=None,
          s_acc: float = 1.0, s_r1: float = 1.0, s_r2: float = 1.0, frame_alpha=None,
          rows_per_alpha: int = 1, r1_blend: bool = False, conv=None,
-         alg_flops_scale: float = 1.0) -> torch.Tensor:
+         alg_flops_scale: float = 1.0, ln=None) -> torch.Tensor:
     """out = epilogue(A @ W^T); see gcd_gemm_desc in include/gcd_amd.h.
 
     conv: dict(Cin, Hi, Wi, Ho, Wo, stride, upsample) for GEMM_CONV3X3 or dict(Cin, T, HW) for
@@ -131,11 +131,27 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mod
     if frame_alpha is not None:
         d.frame_alpha, d.rows_per_alpha, d.r1_blend = frame_alpha.data_ptr(), rows_per_alpha, int(r1_blend)
     d.out_kind = out_kind
+    if ln is not None:
+        # fused LayerNorm of the output rows: dict(gamma, beta, out16[, eps, addvec, rows_per_vec, sum_out])
+        _need_gpu(ln["gamma"], ln["beta"], ln["out16"], ln.get("addvec"), ln.get("sum_out"))
+        d.ln_out16, d.ld_ln_out = ln["out16"].data_ptr(), _ld(ln["out16"])
+        d.ln_gamma, d.ln_beta = ln["gamma"].data_ptr(), ln["beta"].data_ptr()
+        d.ln_eps = ln.get("eps", 1e-5)
+        if ln.get("addvec") is not None:
+            d.ln_addvec, d.ld_ln_addvec = ln["addvec"].data_ptr(), _ld(ln["addvec"])
+            d.ln_rows_per_vec = ln["rows_per_vec"]
+            if ln.get("sum_out") is not None:
+                d.ln_sum_out, d.ld_ln_sum = ln["sum_out"].data_ptr(), _ld(ln["sum_out"])
     expect = torch.float32 if out_kind == OUT_F32 else torch.float16
     assert out.dtype == expect, f"out dtype {out.dtype} does not match out_kind {out_kind}"
     with _Timed("gemm", 2.0 * M * N * K * alg_flops_scale, M=M, N=N, K=K, mode=mode):
         check(_lib.load().gcd_gemm_f16(C.byref(d), _stream()), "gcd_gemm_f16")
     return out
+
+
+def gemm_ln_fusable(M: int, N: int, K: int, mode: int = GEMM_PLAIN) -> bool:
+    """True if `gemm(..., ln=...)` is accepted for this shape (N == 320 on the ping-pong kernel)."""
+    return bool(_lib.load().gcd_gemm_ln_fusable(M, N, K, mode))
 
 
 def linear_smallm(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], y: torch.Tensor, *,

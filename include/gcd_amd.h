@@ -95,6 +95,22 @@ typedef struct gcd_gemm_desc {
   int32_t r1_blend;
   int32_t out_kind;         /* GCD_OUT_* */
   const void* zero_page;    /* >= 256 B of zeros (device), required for conv modes            */
+  /* optional fused LayerNorm of the OUTPUT rows (fp32 out, N == 320 only: one 256x320 tile holds a
+     whole row; see gcd_gemm_ln_fusable):  z = out_row [+ ln_addvec[m / ln_rows_per_vec]],
+     ln_sum_out (optional fp32 [M, N]) = z,  ln_out16 (fp16 [M, N]) = LN(z) * ln_gamma + ln_beta.
+     Replaces the nn.LayerNorm that reads the residual stream right after this GEMM wrote it
+     (attention.py:519-521, video_attention.py:50,90-93, incl. the x + time_pos_embed form of
+     video_attention.py:283-284).                                                                  */
+  void* ln_out16;
+  int64_t ld_ln_out;
+  const float* ln_gamma;
+  const float* ln_beta;
+  float ln_eps;
+  int32_t ln_rows_per_vec;
+  const float* ln_addvec;
+  int64_t ld_ln_addvec;
+  float* ln_sum_out;
+  int64_t ld_ln_sum;
 } gcd_gemm_desc;
 
 /* Replaces torch.nn.Linear / Conv2d / Conv3d forward on the hot path:
@@ -103,6 +119,9 @@ typedef struct gcd_gemm_desc {
  *   311-318 (ResBlock convs, dims=2 and dims=3), openaimodel.py:139-142,199-206 (Up/Downsample),
  *   diffusionmodules/util.py:358-369 (AlphaBlender, folded into the epilogue).                 */
 int gcd_gemm_f16(const gcd_gemm_desc* desc, void* stream);
+/* 1 if gcd_gemm_f16 would accept the descriptor's fused-LayerNorm request for this shape (the
+ * automatic kernel choice lands on the 256x320 ping-pong kernel and N == 320), else 0.          */
+int gcd_gemm_ln_fusable(int M, int N, int K, int mode);
 
 /* y[M,N] (fp32) = [y +] act_out( act_in(x[M,K]) @ W[N,K]^T + b ), fp32 weights, M <= 32.
  * act flags: bit0 = SiLU on input, bit1 = SiLU on output, bit2 = accumulate into y.
