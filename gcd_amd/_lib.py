@@ -40,6 +40,7 @@ class GemmDesc(C.Structure):
         ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("ln_rows_per_vec", C.c_int32),
         ("ln_addvec", C.c_void_p), ("ld_ln_addvec", C.c_int64), ("ln_sum_out", C.c_void_p),
         ("ld_ln_sum", C.c_int64),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 

@@ -340,6 +340,8 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
   k.ld_ln_addvec = d->ld_ln_addvec;
   k.ln_sum_out = d->ln_sum_out;
   k.ld_ln_sum = d->ld_ln_sum;
+  k.splitk = 1;
+  k.split_stride = 0;
   hipStream_t s = (hipStream_t)stream;
 
   // kernel choice: the 256 x 320 ping-pong kernel whenever the grid fills most of the chip with
@@ -348,7 +350,7 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
   bool use_pp = false;
   if (impl != 1 && impl != 5 && impl != 6 && gcd_gemm_pp_supported(k, d->mode)) {
     const int64_t tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 319) / 320);
-    use_pp = impl >= 2 || (impl == 0 && tiles >= 192 && d->N >= 160);
+    use_pp = (impl >= 2 && impl != 7) || ((impl == 0 || impl == 7) && tiles >= 192 && d->N >= 160);
     // K (or the channels per tap) a multiple of 32 but not of 64: only the ping-pong kernel's 32-deep
     // sub-tiles can walk it
     if (d->K % 64 != 0 || (d->mode != GCD_GEMM_PLAIN && d->Cin % 64 != 0)) use_pp = true;
@@ -366,6 +368,19 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
   GCD_CHECK_ARG(use_pp || (d->K % 64 == 0 && (d->mode == GCD_GEMM_PLAIN || d->Cin % 64 == 0)),
                 "gcd_gemm_f16: K=%d (Cin=%d) needs the ping-pong kernel, which the shape or "
                 "GCD_TUNE_GEMM_IMPL=%d rules out", d->K, d->Cin, impl);
+
+  // split-K: few 256x320 tiles (<= 96 of 256 CUs) and a long K — the 3x3 convs of the 9x16 level
+  if (d->workspace && !d->ln_out16 && d->out_kind != GCD_OUT_GEGLU && (impl == 0 || impl == 7) &&
+      gcd_gemm_pp_supported(k, d->mode) && d->N >= 160 && d->N % 4 == 0) {
+    const int64_t tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 319) / 320);
+    int splitk = (int)(256 / tiles);
+    if (splitk > 4) splitk = 4;
+    if (tiles <= 96 && splitk >= 2 && d->K / splitk >= 1920 &&
+        d->workspace_bytes >= (int64_t)splitk * d->M * d->N * 4 && ((uintptr_t)d->workspace & 15) == 0) {
+      if (d->mode != GCD_GEMM_PLAIN) GCD_CHECK_ARG(d->zero_page, "gcd_gemm_f16: conv mode needs a zero page");
+      return gcd_gemm_pp_launch_splitk(k, d->mode, splitk, (float*)d->workspace, s);
+    }
+  }
 
   switch (d->mode) {
     case GCD_GEMM_PLAIN:

@@ -36,11 +36,18 @@ struct GemmK {
   int64_t ld_ln_addvec;
   float* ln_sum_out;
   int64_t ld_ln_sum;
+  // split-K (gemm_pp.hip): workgroup L works on tile L / splitk, K slice L % splitk, and stores raw
+  // fp32 partial sums at out + slice * split_stride (elements)
+  int splitk;
+  int64_t split_stride;
 };
 
 // gemm_pp.hip: the 256 x 320 ping-pong kernel.
 bool gcd_gemm_pp_supported(const GemmK& k, int mode);
 int gcd_gemm_pp_launch(const GemmK& k, int mode, hipStream_t s);
+
+// gemm_pp.hip: split-K launch = partial sums into `ws` + reduce-and-epilogue kernel.
+int gcd_gemm_pp_launch_splitk(const GemmK& k, int mode, int splitk, float* ws, hipStream_t s);
 
 // runtime.hip: tuning knobs (gcd_tune_set / environment), see include/gcd_amd.h
 int gcd_tune_get(int knob);

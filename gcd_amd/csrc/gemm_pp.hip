@@ -74,17 +74,25 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
   }
   for (; L < L_end; L += L_step) {
   int tile_m, tile_n;
+  const int kz = (VAR & 16384) ? L % p.splitk : 0;          // split-K: K slice of this workgroup
   {
+    const int Lt = (VAR & 16384) ? L / p.splitk : L;
     const int per_group = PP_GROUP_M * p.tiles_n;
-    const int gi = L / per_group;
-    const int rem = L - gi * per_group;
+    const int gi = Lt / per_group;
+    const int rem = Lt - gi * per_group;
     const int m_first = gi * PP_GROUP_M;
     const int gm = min(PP_GROUP_M, p.tiles_m - m_first);
     tile_n = rem / gm;
     tile_m = m_first + rem - tile_n * gm;
   }
   const int m0 = tile_m * PP_BM, n0 = tile_n * PP_BN;
-  const int S = p.K >> 5;               // number of 32-deep sub-tiles
+  // 32-deep sub-tiles of this workgroup: all of K, or slice kz of it
+  int s_begin = 0, S = p.K >> 5;
+  if (VAR & 16384) {
+    const int per = (S + p.splitk - 1) / p.splitk;
+    s_begin = kz * per;
+    S = min(per, S - s_begin);
+  }
 
   // ---- DMA bookkeeping: a piece = 16 rows x 64 B = one global_load_lds_dwordx4 of a wave ----
   const int lrow = lane >> 2;
@@ -146,14 +154,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
       }
     }
   };
-  int a_tap = 0, a_c0 = 0;   // K position of the next A issue (conv modes), block-uniform
+  // K position of the next A issue (conv modes), block-uniform
+  int a_tap = (MODE != GCD_GEMM_PLAIN) ? (s_begin * 32) / p.Cin : 0;
+  int a_c0 = (MODE != GCD_GEMM_PLAIN) ? s_begin * 32 - a_tap * p.Cin : 0;
   bool dma_on = true;
   auto issue_A = [&](int sigma) {
     if (sigma < S && dma_on) {
       char* dst = smem + (sigma & 3) * PP_SLOT + wave * 2048;
       if (MODE == GCD_GEMM_PLAIN) {
-        glds16(a_base[0] + sigma * 64, dst);
-        glds16(a_base[1] + sigma * 64, dst + 1024);
+        glds16(a_base[0] + (s_begin + sigma) * 64, dst);
+        glds16(a_base[1] + (s_begin + sigma) * 64, dst + 1024);
       } else {
         glds16(a_base[0] + a_c0 * a_inc[0], dst);
         glds16(a_base[1] + a_c0 * a_inc[1], dst + 1024);
@@ -179,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
   }
   auto issue_W = [&](int j, int sigma) {
     if (sigma < S && dma_on)
-      glds16(w_base[j] + sigma * 64,
+      glds16(w_base[j] + (s_begin + sigma) * 64,
              smem + (sigma & 3) * PP_SLOT + PP_A_BYTES + (w_first + j) * 1024);
   };
 
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
   } while (0)
 
   // ---- prologue: sub-tiles 0, 1 and (group 0: the first part of) 2, in steady-state order ----
-  if (MODE != GCD_GEMM_PLAIN) set_tap(0);
+  if (MODE != GCD_GEMM_PLAIN) set_tap(a_tap);
   if (grp == 0) {
 #pragma unroll
     for (int sg = 0; sg < 2; ++sg) {
@@ -314,7 +324,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
 
   // ---- epilogue (gemm_common.h): LDS-transposed, 128-byte-row global accesses.  Every wave is
   //      past its last fragment read of the ring (see the barrier structure above). ----
-  if constexpr ((VAR & 8192) != 0)   // own instantiation: fused LayerNorm of the output rows (N == 320)
+  if constexpr ((VAR & 16384) != 0) {   // split-K: raw fp32 partial sums of this K slice
+    GemmK q = p;
+    q.out = (float*)p.out + (int64_t)kz * p.split_stride;
+    gcd_epilogue_64x160<8>(q, acc, m0 + 64 * wm, n0 + 160 * wn, lane, smem);
+  } else if constexpr ((VAR & 8192) != 0)   // own instantiation: fused LayerNorm (N == 320)
     gcd_epilogue_64x160_ln(p, acc, m0 + 64 * wm, n0 + 160 * wn, lane, wm, wn, (float*)smem);
   else
     gcd_epilogue_64x160<((VAR >> 6) & 31)>(p, acc, m0 + 64 * wm, n0 + 160 * wn, lane,
@@ -343,7 +357,89 @@ int launch_pp(const GemmK& k, hipStream_t s) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// split-K: sum the K-slice partials and run the epilogue (bias, per-frame vectors, residuals with
+// AlphaBlender scales, fp32 / fp16 out) on 16-byte vectors.  grid-stride over M * N / 4.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmK p, const float* __restrict__ ws,
+                                                            int splitk) {
+  const int nv = p.N >> 2;
+  const int64_t total = (int64_t)p.M * nv;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * 256) {
+    const int m = (int)(idx / nv);
+    const int n = (int)(idx - (int64_t)m * nv) * 4;
+    f32x4 v = *(const f32x4*)(ws + (int64_t)m * p.N + n);
+    for (int z = 1; z < splitk; ++z) v += *(const f32x4*)(ws + z * p.split_stride + (int64_t)m * p.N + n);
+    float sa = p.s_acc, sr1 = p.s_r1, sr2 = p.s_r2;
+    if (p.frame_alpha) {
+      const float al = p.frame_alpha[m / p.rows_per_alpha];
+      sa = 1.0f - al;
+      sr2 = al;
+      if (p.r1_blend) sr1 *= 1.0f - al;
+    }
+    if (p.bias) v += *(const f32x4*)(p.bias + n);
+    if (p.rowvec) v += *(const f32x4*)(p.rowvec + (int64_t)(m / p.rows_per_vec) * p.ld_rowvec + n);
+    v *= sa;
+    if (p.R1) v += sr1 * *(const f32x4*)(p.R1 + (int64_t)m * p.ldr1 + n);
+    if (p.R2) v += sr2 * *(const f32x4*)(p.R2 + (int64_t)m * p.ldr2 + n);
+    if (p.out_kind == GCD_OUT_F32) {
+      *(f32x4*)((float*)p.out + (int64_t)m * p.ldo + n) = v;
+    } else {
+      f16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (f16)v[e];
+      *(f16x4*)((f16*)p.out + (int64_t)m * p.ldo + n) = o;
+    }
+  }
+}
+
+template <int MODE>
+int launch_pp_splitk(const GemmK& k, int splitk, float* ws, hipStream_t s) {
+  static bool attr_set = false;
+  auto fn = gemm_pp_kernel<MODE, 16384>;
+  if (!attr_set) {
+    GCD_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      PP_SMEM));
+    attr_set = true;
+  }
+  GemmK kk = k;
+  kk.tiles_m = (k.M + PP_BM - 1) / PP_BM;
+  kk.tiles_n = (k.N + PP_BN - 1) / PP_BN;
+  kk.splitk = splitk;
+  kk.split_stride = (int64_t)k.M * k.N;
+  // the GEMM pass writes plain partial sums [splitk][M][N]; the epilogue inputs go to the reduce pass
+  kk.out = ws;
+  kk.ldo = k.N;
+  kk.out_kind = GCD_OUT_F32;
+  kk.bias = kk.rowvec = kk.R1 = kk.R2 = kk.frame_alpha = nullptr;
+  kk.s_acc = 1.0f;
+  kk.ln_out = nullptr;
+  const int64_t nblk = (int64_t)kk.tiles_m * kk.tiles_n * splitk;
+  hipLaunchKernelGGL(fn, dim3((unsigned)nblk), dim3(512), PP_SMEM, s, kk);
+  GCD_CHECK_LAUNCH();
+  GemmK kr = k;
+  kr.split_stride = kk.split_stride;
+  const int64_t nvec = (int64_t)k.M * (k.N >> 2);
+  int64_t rb = (nvec + 255) / 256;
+  if (rb > 4096) rb = 4096;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, s, kr, ws, splitk);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
 }  // namespace
+
+int gcd_gemm_pp_launch_splitk(const GemmK& k, int mode, int splitk, float* ws, hipStream_t s) {
+  switch (mode) {
+    case GCD_GEMM_PLAIN:
+      return launch_pp_splitk<GCD_GEMM_PLAIN>(k, splitk, ws, s);
+    case GCD_GEMM_CONV3X3:
+      return launch_pp_splitk<GCD_GEMM_CONV3X3>(k, splitk, ws, s);
+    default:
+      return launch_pp_splitk<GCD_GEMM_TEMPORAL3>(k, splitk, ws, s);
+  }
+}
 
 // Shapes the ping-pong kernel accepts (the caller has validated the descriptor already).
 bool gcd_gemm_pp_supported(const GemmK& k, int mode) {

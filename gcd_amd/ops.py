@@ -7,6 +7,7 @@ Token-major convention: an activation of `frames x H x W x C` is a 2-D tensor [f
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -91,6 +92,21 @@ def zero_page(device) -> torch.Tensor:
     return z
 
 
+_splitk = {}
+_SPLITK_ON = os.environ.get("GCD_SPLITK", "1") != "0"   # A/B switch
+
+
+def _splitk_ws(device) -> torch.Tensor:
+    """Persistent split-K scratch per device (gcd_gemm_desc.workspace): 4 partial outputs of the
+    largest few-tile problem of the SVD UNet, 4032 tokens x 1280 channels fp32 = 83 MB."""
+    key = torch.device(device).index or 0
+    w = _splitk.get(key)
+    if w is None:
+        w = torch.empty(4 * 4096 * 1280, dtype=torch.float32, device=device)
+        _splitk[key] = w
+    return w
+
+
 def _ld(t: torch.Tensor) -> int:
     assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D view"
     return t.stride(0)
@@ -142,6 +158,9 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mod
             d.ln_rows_per_vec = ln["rows_per_vec"]
             if ln.get("sum_out") is not None:
                 d.ln_sum_out, d.ld_ln_sum = ln["sum_out"].data_ptr(), _ld(ln["sum_out"])
+    if _SPLITK_ON:
+        sk = _splitk_ws(a16.device)
+        d.workspace, d.workspace_bytes = sk.data_ptr(), sk.numel() * 4
     expect = torch.float32 if out_kind == OUT_F32 else torch.float16
     assert out.dtype == expect, f"out dtype {out.dtype} does not match out_kind {out_kind}"
     with _Timed("gemm", 2.0 * M * N * K * alg_flops_scale, M=M, N=N, K=K, mode=mode):

@@ -42,7 +42,7 @@ int gcd_device_info(int device, char* name, int cap, int* num_cus, size_t* hbm_b
  * GCD_GEMM_IMPL / GCD_ATTN_IMPL.
  *   GCD_TUNE_GEMM_IMPL: 0 = automatic, 1 = general 128-row kernel, 2 = 256x320 ping-pong kernel,
  *                       4 = ping-pong kernel, never persistent; 5 / 6 = general kernel, never / always
- *                       64-row tiles; >= 32: ablation builds (gemm_pp.hip)
+ *                       64-row tiles; 7 = like 0 (split-K allowed, used by tests); >= 32: ablation builds
  *   GCD_TUNE_ATTN_IMPL: 0 = automatic, other values select spatial-attention kernel variants   */
 #define GCD_TUNE_GEMM_IMPL 0
 #define GCD_TUNE_ATTN_IMPL 1
@@ -111,6 +111,12 @@ typedef struct gcd_gemm_desc {
   int64_t ld_ln_addvec;
   float* ln_sum_out;
   int64_t ld_ln_sum;
+  /* optional scratch (device, 16-byte aligned): lets gcd_gemm_f16 split K over several workgroups
+     when the output has too few 256x320 tiles to fill the chip (the 9x16 bottleneck level: 64 tiles
+     on 256 CUs) — fp32 partial sums [splits][M][N] + one reduce-and-epilogue launch.  Needs
+     4 * M * N * 4 bytes to be used; NULL or too small = never split.                               */
+  void* workspace;
+  int64_t workspace_bytes;
 } gcd_gemm_desc;
 
 /* Replaces torch.nn.Linear / Conv2d / Conv3d forward on the hot path:

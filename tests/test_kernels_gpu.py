@@ -100,6 +100,42 @@ def test_gemm_fused_layernorm(gpu, gemm_impl, M, K, with_pos):
     assert e < TOL_F16, f"fused LayerNorm rel-L2 {e:.3e}"
 
 
+def test_gemm_split_k(gpu, gemm_impl):
+    """Few output tiles and a long K: the automatic choice splits K over 4 workgroups per tile (fp32
+    partial sums in the scratch + a reduce kernel that runs the whole epilogue).  Linear and 3x3 conv."""
+    from gcd_amd import ops, packing
+    g = _gen(24)
+    M, N, K = 1000, 640, 7680
+    a = _h(torch.randn(M, K, generator=g))
+    w = _h(torch.randn(N, K, generator=g) / math.sqrt(K))
+    bias = torch.randn(N, generator=g)
+    r1, r2 = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    rows = 125
+    alpha = torch.rand(M // rows, generator=g)
+    al = alpha.repeat_interleave(rows)[:, None]
+    ref = al * r2 + (1 - al) * (a @ w.t() + bias + r1)
+    out = torch.empty(M, N, device=gpu)
+    ops.gemm(a.half().to(gpu), w.half().to(gpu), out, M=M, bias=bias.to(gpu), r1=r1.to(gpu),
+             r2=r2.to(gpu), frame_alpha=alpha.to(gpu), rows_per_alpha=rows, r1_blend=True)
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < TOL_F32
+    out16 = torch.empty(M, N, device=gpu, dtype=torch.float16)
+    ops.gemm(a.half().to(gpu), w.half().to(gpu), out16, M=M, out_kind=ops.OUT_F16)
+    torch.cuda.synchronize()
+    assert rel_l2(out16.float(), a @ w.t()) < TOL_F16
+    frames, Cin, Cout, H, W = 4, 896, 320, 9, 16           # K = 8064: slices start mid-tap
+    x = _h(torch.randn(frames, Cin, H, W, generator=g))
+    wc = _h(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    b = torch.randn(Cout, generator=g)
+    refc = F.conv2d(x, wc, b, padding=1).permute(0, 2, 3, 1).reshape(frames * H * W, Cout)
+    ac = x.permute(0, 2, 3, 1).reshape(frames * H * W, Cin).half().to(gpu)
+    outc = torch.empty(frames * H * W, Cout, device=gpu)
+    ops.gemm(ac, packing.pack_conv3x3(wc).to(gpu), outc, M=frames * H * W, mode=ops.GEMM_CONV3X3,
+             bias=b.to(gpu), conv=dict(Cin=Cin, Hi=H, Wi=W, Ho=H, Wo=W, stride=1, upsample=0))
+    torch.cuda.synchronize()
+    assert rel_l2(outc, refc) < TOL_F32
+
+
 def test_conv3x3_pingpong_full_tiles(gpu, gemm_impl):
     """A conv whose grid fills whole 256 x 320 tiles (what the automatic choice sends to the ping-pong
     kernel): 320 -> 320 channels on 28 frames of 24 x 32, stride 1 / stride 2 / fused x2 upsample."""

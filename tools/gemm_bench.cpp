@@ -181,6 +181,12 @@ int main(int argc, char** argv) {
     d.upsample = s.up; d.T = s.T; d.HW = s.HW; d.bias = bias; d.s_acc = d.s_r1 = d.s_r2 = 1.0f;
     d.out_kind = geglu ? GCD_OUT_GEGLU : f16out ? GCD_OUT_F16 : GCD_OUT_F32;
     d.zero_page = zero;
+    float* skws = nullptr;   // split-K scratch, only for the few-tile shapes that can use it
+    if ((int64_t)((s.M + 255) / 256) * ((s.N + 319) / 320) <= 96) {
+      CK(hipMalloc(&skws, (size_t)4 * s.M * s.N * 4));
+      d.workspace = skws;
+      d.workspace_bytes = (int64_t)4 * s.M * s.N * 4;
+    }
     if (r1) { d.R1 = r1; d.ldr1 = ncols; }
     if (s.epi == 4) {
       d.R2 = r2; d.ldr2 = ncols; d.rowvec = rv; d.ld_rowvec = s.N; d.rows_per_vec = rows_per_frame;
@@ -278,6 +284,7 @@ int main(int argc, char** argv) {
     if (r2) hipFree(r2);
     if (rv) hipFree(rv);
     if (alpha) hipFree(alpha);
+    if (skws) hipFree(skws);
   }
   printf("weighted by launches/step: legacy %.2f ms (%.0f TF/s)  pp %.2f ms (%.0f TF/s)  over %.1f TFLOP\n",
          tot_ms[0], tot_fl / tot_ms[0] * 1e-9, tot_ms[1], tot_fl / tot_ms[1] * 1e-9, tot_fl * 1e-12);
