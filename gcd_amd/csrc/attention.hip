@@ -326,15 +326,44 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
     const int64_t b = ps / HW;
     row = (b * T + i) * HW + s;
   }
+  // K / V rows -> LDS with a cooperative, coalesced map: thread t always serves problem (t >> 3) & 15
+  // and 16-byte chunk t & 7, and walks the 2 T (k|v, frame) rows with stride 2 — consecutive
+  // threads read consecutive 16-byte chunks of one row, and consecutive problems (= heads of the same
+  // pixel) are adjacent in memory, so a wave-instruction covers whole 128-byte lines instead of 64
+  // scattered 16-byte pieces.
+  {
+    const int lp = (t >> 3) & 15, cc = t & 7;
+    const int64_t lpid = (int64_t)blockIdx.x * TPROB + lp;
+    if (lpid < nprob) {
+      const int lh = (int)(lpid % heads);
+      const int64_t lps = lpid / heads;
+      const int ls = (int)(lps % HW);
+      const int64_t lb = lps / HW;
+      const f16* base = qkv + ((lb * T) * HW + ls) * ld + lh * 64 + cc * 8;
+      char* kdst = smem + lp * pstride + cc * 16;
+      char* vdst = smem + TPROB * pstride + lp * pstride + cc * 16;
+      f16x8 tmp[16];   // all loads in flight before the first LDS write (T <= 16 -> <= 16 rows each)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int wi = (t >> 7) + 2 * j;
+        const int which = wi >= T ? 1 : 0;          // 0: k rows, 1: v rows
+        const int fi = wi - which * T;
+        if (wi < 2 * T) tmp[j] = *(const f16x8*)(base + (int64_t)fi * HW * ld + (which + 1) * C);
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int wi = (t >> 7) + 2 * j;
+        const int which = wi >= T ? 1 : 0;
+        const int fi = wi - which * T;
+        if (wi < 2 * T) *(f16x8*)((which ? vdst : kdst) + fi * 128) = tmp[j];
+      }
+    }
+  }
   f16x8 q[8];
   if (valid) {
     const f16* src = qkv + row * ld + h * 64;
 #pragma unroll
-    for (int cc = 0; cc < 8; ++cc) {
-      q[cc] = *(const f16x8*)(src + cc * 8);
-      *(f16x8*)(Kp + i * 128 + cc * 16) = *(const f16x8*)(src + C + cc * 8);
-      *(f16x8*)(Vp + i * 128 + cc * 16) = *(const f16x8*)(src + 2 * C + cc * 8);
-    }
+    for (int cc = 0; cc < 8; ++cc) q[cc] = *(const f16x8*)(src + cc * 8);
   } else {
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) q[cc] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};

@@ -72,7 +72,7 @@ int gcd_tune_get(int knob);
 // shape: stores alone +40 us, residual loads alone +100 us, both +215 us on 258048 x 320), so fp32
 // and GEGLU outputs are written straight from the accumulator layout.
 // EV: experiment switches for tools/gemm_bench (0 = product): 1 skip residual loads, 2 skip stores,
-// 4 nontemporal stores, 8 force the direct path, 16 force the transposed path
+// 4 nontemporal stores, 8 force the direct path, 16 force the transposed path, 32 no epilogue at all
 // Fused LayerNorm (p.ln_out != nullptr, N == 320 == the tile width, fp32 out): the two waves that
 // share a 64-token row block (wn = 0 / 1, 160 channels each) exchange per-row sum and sum of squares
 // through `red` (LDS, >= 4 KB, workgroup-shared; ONE __syncthreads, so every thread of the workgroup
@@ -172,6 +172,14 @@ template <int EV = 0>
 __device__ __forceinline__ void gcd_epilogue_64x160(const GemmK& p, f32x16 (&acc)[5][2], int m_base,
                                                     int n_base, int lane, char* stage) {
   const int l31 = lane & 31, hh = lane >> 5;
+  if (EV & 32) {   // experiment: no epilogue at all (mainloop-only timing); never set by VAR decoding of
+                   // the product kernels (gemm_pp.hip maps VAR bit 32768 to it)
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
   if ((EV & 16) && p.out_kind == GCD_OUT_GEGLU && p.N % 320 == 0 && (p.ldo & 7) == 0) {
     // a * gelu(g) in the accumulator layout (value / gate live in the same lane), staged as fp16
     // [64 rows][80 hidden columns], written out as 160 contiguous bytes per row.

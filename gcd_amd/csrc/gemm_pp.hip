@@ -331,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
   } else if constexpr ((VAR & 8192) != 0)   // own instantiation: fused LayerNorm (N == 320)
     gcd_epilogue_64x160_ln(p, acc, m0 + 64 * wm, n0 + 160 * wn, lane, wm, wn, (float*)smem);
   else
-    gcd_epilogue_64x160<((VAR >> 6) & 31)>(p, acc, m0 + 64 * wm, n0 + 160 * wn, lane,
+    gcd_epilogue_64x160<(((VAR >> 6) & 31) | ((VAR & 32768) ? 32 : 0))>(p, acc, m0 + 64 * wm, n0 + 160 * wn, lane,
                                            smem + wave * GCD_EPI_STAGE_BYTES);
   if (PERSIST) __syncthreads();   // epilogue LDS use vs the next tile's prologue DMA
   }   // tile loop
@@ -464,6 +464,7 @@ int gcd_gemm_pp_launch(const GemmK& k, int mode, hipStream_t s) {
       case 19 + 128: return launch_pp<GCD_GEMM_PLAIN, 19 + 128>(k, s);    // no stores
       case 19 + 192: return launch_pp<GCD_GEMM_PLAIN, 19 + 192>(k, s);    // neither
       case 1024: return launch_pp<GCD_GEMM_PLAIN, 1024>(k, s);            // transposed epilogue forced
+      case 2048 + 32768: return launch_pp<GCD_GEMM_PLAIN, 2048 + 32768>(k, s);   // persistent, no epilogue
       default: break;
     }
   }
