@@ -243,8 +243,9 @@ __device__ __forceinline__ void gcd_epilogue_64x160(const GemmK& p, f32x16 (&acc
           }
           f16x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (f16)(a[e] * gelu_fast(gt[e]));
-          *(f16x4*)((f16*)p.out + (int64_t)m * p.ldo + (nb >> 1) + c) = o;
+          for (int e = 0; e < 4; ++e) o[e] = (f16)((EV & 4) ? a[e] * gt[e] : a[e] * gelu_fast(gt[e]));
+          if (EV & 2) asm volatile("" ::"v"(o));
+          else *(f16x4*)((f16*)p.out + (int64_t)m * p.ldo + (nb >> 1) + c) = o;
         }
       }
     }

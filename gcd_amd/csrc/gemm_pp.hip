@@ -465,6 +465,9 @@ int gcd_gemm_pp_launch(const GemmK& k, int mode, hipStream_t s) {
       case 19 + 192: return launch_pp<GCD_GEMM_PLAIN, 19 + 192>(k, s);    // neither
       case 1024: return launch_pp<GCD_GEMM_PLAIN, 1024>(k, s);            // transposed epilogue forced
       case 2048 + 32768: return launch_pp<GCD_GEMM_PLAIN, 2048 + 32768>(k, s);   // persistent, no epilogue
+      case 2048 + 128: return launch_pp<GCD_GEMM_PLAIN, 2048 + 128>(k, s);       // persistent, no stores
+      case 2048 + 256: return launch_pp<GCD_GEMM_PLAIN, 2048 + 256>(k, s);       // persistent, GEGLU without GELU
+      case 2048 + 384: return launch_pp<GCD_GEMM_PLAIN, 2048 + 384>(k, s);       // neither
       default: break;
     }
   }

@@ -181,11 +181,13 @@ int main(int argc, char** argv) {
     d.upsample = s.up; d.T = s.T; d.HW = s.HW; d.bias = bias; d.s_acc = d.s_r1 = d.s_r2 = 1.0f;
     d.out_kind = geglu ? GCD_OUT_GEGLU : f16out ? GCD_OUT_F16 : GCD_OUT_F32;
     d.zero_page = zero;
-    float* skws = nullptr;   // split-K scratch, only for the few-tile shapes that can use it
-    if ((int64_t)((s.M + 255) / 256) * ((s.N + 319) / 320) <= 96) {
-      CK(hipMalloc(&skws, (size_t)4 * s.M * s.N * 4));
+    float* skws = nullptr;   // scratch: split-K partials for the few-tile shapes, per-CU counters else
+    {
+      size_t wsb = 65536;
+      if ((int64_t)((s.M + 255) / 256) * ((s.N + 319) / 320) <= 96) wsb = (size_t)4 * s.M * s.N * 4;
+      CK(hipMalloc(&skws, wsb));
       d.workspace = skws;
-      d.workspace_bytes = (int64_t)4 * s.M * s.N * 4;
+      d.workspace_bytes = (int64_t)wsb;
     }
     if (r1) { d.R1 = r1; d.ldr1 = ncols; }
     if (s.epi == 4) {
