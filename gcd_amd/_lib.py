@@ -63,6 +63,9 @@ SIGNATURES = {
     "gcd_attn_transpose_v": (_i, [_vp, _i64, _i, _i, _i, _vp, _i, _vp]),
     "gcd_attn_spatial_f16": (_i, [_vp, _i64, _vp, _i, _vp, _i64, _i, _i, _i, _i, _vp]),
     "gcd_attn_temporal_f16": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "gcd_softmax_rows_f16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),
+    "gcd_transpose_f16": (_i, [_vp, _i64, _vp, _i64, _i, _i, _vp]),
+    "gcd_time_mix_unpack": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "gcd_pack_input": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp]),
     "gcd_unpack_output": (_i, [_vp, _i64, _vp, _i, _i, _i, _vp]),
     "gcd_cast_f32_f16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),

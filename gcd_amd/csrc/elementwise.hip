@@ -181,6 +181,77 @@ extern "C" int gcd_unpack_output(const float* in, int64_t ld, float* out, int Co
   return 0;
 }
 
+// AE3DConv's time_mix_conv (Conv3d C -> C, kernel (3,1,1), zero padded in time) fused with the
+// token-major -> NCHW layout change:
+//   out[n][co][p] = b[co] + sum_{dt, ci} w[co][ci][dt] * in[((n + dt - 1) * HW + p) * ld + ci]
+// for frames n + dt - 1 inside the clip of T frames that holds n.  C <= 4 (RGB): HBM-bound.
+template <int C>
+__global__ __launch_bounds__(256) void time_mix_unpack_kernel(const float* __restrict__ in, int64_t ld,
+                                                              const float* __restrict__ w,
+                                                              const float* __restrict__ b,
+                                                              float* __restrict__ out, int N, int T,
+                                                              int HW) {
+  float wr[C][C][3], br[C];
+#pragma unroll
+  for (int co = 0; co < C; ++co) {
+    br[co] = b[co];
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci)
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt) wr[co][ci][dt] = w[(co * C + ci) * 3 + dt];
+  }
+  const int64_t total = (int64_t)N * HW;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * 256) {
+    const int n = (int)(idx / HW);
+    const int p = (int)(idx - (int64_t)n * HW);
+    const int t = n % T;
+    float acc[C];
+#pragma unroll
+    for (int co = 0; co < C; ++co) acc[co] = br[co];
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) {
+      const int tt = t + dt - 1;
+      if (tt < 0 || tt >= T) continue;
+      const float* src = in + (idx + (int64_t)(dt - 1) * HW) * ld;
+      float v[C];
+      if (C == 4) {
+        const f32x4 q = *(const f32x4*)src;
+#pragma unroll
+        for (int ci = 0; ci < C; ++ci) v[ci] = q[ci];
+      } else {
+#pragma unroll
+        for (int ci = 0; ci < C; ++ci) v[ci] = src[ci];
+      }
+#pragma unroll
+      for (int co = 0; co < C; ++co)
+#pragma unroll
+        for (int ci = 0; ci < C; ++ci) acc[co] = fmaf(wr[co][ci][dt], v[ci], acc[co]);
+    }
+#pragma unroll
+    for (int co = 0; co < C; ++co) out[((int64_t)n * C + co) * HW + p] = acc[co];
+  }
+}
+
+extern "C" int gcd_time_mix_unpack(const float* in, int64_t ld, const float* w, const float* b,
+                                   float* out, int C, int N, int T, int HW, void* stream) {
+  GCD_CHECK_ARG(in && w && b && out, "gcd_time_mix_unpack: null pointer");
+  GCD_CHECK_ARG(C >= 1 && C <= 4 && N > 0 && T > 0 && N % T == 0 && HW > 0 && ld >= C && ld % 4 == 0,
+                "gcd_time_mix_unpack: C=%d (1..4) N=%d T=%d HW=%d ld=%lld", C, N, T, HW, (long long)ld);
+  int64_t blocks = ((int64_t)N * HW + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  const dim3 g((unsigned)blocks), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (C) {
+    case 1: hipLaunchKernelGGL(time_mix_unpack_kernel<1>, g, blk, 0, s, in, ld, w, b, out, N, T, HW); break;
+    case 2: hipLaunchKernelGGL(time_mix_unpack_kernel<2>, g, blk, 0, s, in, ld, w, b, out, N, T, HW); break;
+    case 3: hipLaunchKernelGGL(time_mix_unpack_kernel<3>, g, blk, 0, s, in, ld, w, b, out, N, T, HW); break;
+    default: hipLaunchKernelGGL(time_mix_unpack_kernel<4>, g, blk, 0, s, in, ld, w, b, out, N, T, HW); break;
+  }
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
 // fp32 [M, C] (ld) -> fp16 [M, C] (ld), C % 8 == 0
 __global__ __launch_bounds__(256) void cast_f32_f16_kernel(const float* __restrict__ x, int64_t ldx,
                                                            f16* __restrict__ y, int64_t ldy,
@@ -212,6 +283,106 @@ extern "C" int gcd_cast_f32_f16(const float* x, int64_t ldx, void* y16, int64_t 
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(cast_f32_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      x, ldx, (f16*)y16, ldy, M, C);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pieces of the first-stage VideoDecoder's single-head mid attention (head dim = 512 channels, so it
+// runs as two GEMMs with these two kernels in between; diffusionmodules/model.py:164-202).
+//   softmax over the rows of an fp32 score matrix -> fp16 probabilities; one workgroup per row, the
+//   row lives in registers (C <= 16384), max / sum by wavefront shuffles + LDS;
+//   fp16 [R, C] -> [C, R] transpose through a padded 64 x 64 LDS tile (V -> V^T, the "W" operand of P V).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int64_t ldx,
+                                                           f16* __restrict__ y, int64_t ldy, int C) {
+  __shared__ float red[8];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* row = x + (int64_t)blockIdx.x * ldx;
+  f32x4 v[16];
+  const int cv4 = C >> 2;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = t + 256 * i;
+    if (c < cv4) {
+      v[i] = *(const f32x4*)(row + c * 4);
+      mx = fmaxf(fmaxf(mx, fmaxf(v[i][0], v[i][1])), fmaxf(v[i][2], v[i][3]));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = t + 256 * i;
+    if (c < cv4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[i][e] = __expf(v[i][e] - mx);
+        sum += v[i][e];
+      }
+    }
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  f16* out = y + (int64_t)blockIdx.x * ldy;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = t + 256 * i;
+    if (c < cv4) {
+      f16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (f16)(v[i][e] * inv);
+      *(f16x4*)(out + c * 4) = o;
+    }
+  }
+}
+
+extern "C" int gcd_softmax_rows_f16(const float* x, int64_t ldx, void* y16, int64_t ldy, int64_t R,
+                                    int C, void* stream) {
+  GCD_CHECK_ARG(x && y16, "gcd_softmax_rows_f16: null pointer");
+  GCD_CHECK_ARG(R > 0 && R < (1ll << 31) && C > 0 && C % 4 == 0 && C <= 16384 && ldx % 4 == 0 &&
+                    ldy % 4 == 0,
+                "gcd_softmax_rows_f16: R=%lld C=%d (C %% 4 == 0, <= 16384) ldx=%lld ldy=%lld",
+                (long long)R, C, (long long)ldx, (long long)ldy);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     (f16*)y16, ldy, C);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void transpose_f16_kernel(const f16* __restrict__ x, int64_t ldx,
+                                                            f16* __restrict__ y, int64_t ldy, int R,
+                                                            int C) {
+  __shared__ f16 tile[64][66];
+  const int t = threadIdx.x;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = (t >> 6) + 4 * i, c = t & 63;
+    tile[r][c] = (r0 + r < R && c0 + c < C) ? x[(int64_t)(r0 + r) * ldx + c0 + c] : (f16)0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = (t >> 6) + 4 * i, r = t & 63;
+    if (c0 + c < C && r0 + r < R) y[(int64_t)(c0 + c) * ldy + r0 + r] = tile[r][c];
+  }
+}
+
+extern "C" int gcd_transpose_f16(const void* x, int64_t ldx, void* y, int64_t ldy, int R, int C,
+                                 void* stream) {
+  GCD_CHECK_ARG(x && y, "gcd_transpose_f16: null pointer");
+  GCD_CHECK_ARG(R > 0 && C > 0 && ldx >= C && ldy >= R, "gcd_transpose_f16: R=%d C=%d ldx=%lld ldy=%lld",
+                R, C, (long long)ldx, (long long)ldy);
+  hipLaunchKernelGGL(transpose_f16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0,
+                     (hipStream_t)stream, (const f16*)x, ldx, (f16*)y, ldy, R, C);
   GCD_CHECK_LAUNCH();
   return 0;
 }

@@ -187,11 +187,11 @@ def linear_smallm(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], y
     return y
 
 
-def gn_nchunks(rows_per_inst: int, ninst: int = 1) -> int:
+def gn_nchunks(rows_per_inst: int, ninst: int = 1, cap: int = 256) -> int:
     """Row chunks per GroupNorm instance for the statistics pass: ~1500 workgroups over the whole
-    launch (6 per CU), never less than 64 rows per chunk, at most 256 chunks per instance."""
+    launch (6 per CU), never less than 64 rows per chunk, at most `cap` chunks per instance."""
     want = max(1, -(-1536 // max(1, ninst)))
-    return max(1, min(256, want, (rows_per_inst + 63) // 64))
+    return max(1, min(cap, want, (rows_per_inst + 63) // 64))
 
 
 def groupnorm_stats(x1, x2, rows_per_inst: int, eps: float, partial: torch.Tensor,
@@ -262,6 +262,36 @@ def attn_temporal(qkv16, out16, clips: int, T: int, HW: int, heads: int):
                                             _ld(out16), clips, T, HW, heads, _stream()),
           "gcd_attn_temporal_f16")
     return out16
+
+
+def softmax_rows(x32, y16):
+    """y16[r] = softmax(x32[r]) (fp32 scores -> fp16 probabilities), rows of length C <= 16384."""
+    _need_gpu(x32, y16)
+    R, Cc = x32.shape
+    check(_lib.load().gcd_softmax_rows_f16(x32.data_ptr(), _ld(x32), y16.data_ptr(), _ld(y16), R, Cc,
+                                           _stream()), "gcd_softmax_rows_f16")
+    return y16
+
+
+def transpose_f16(x16, y16):
+    """y16 [C, R] = x16 [R, C]^T (fp16)."""
+    _need_gpu(x16, y16)
+    R, Cc = x16.shape
+    assert y16.shape == (Cc, R)
+    check(_lib.load().gcd_transpose_f16(x16.data_ptr(), _ld(x16), y16.data_ptr(), _ld(y16), R, Cc,
+                                        _stream()), "gcd_transpose_f16")
+    return y16
+
+
+def time_mix_unpack(tok32, w, b, out_nchw, C: int, N: int, T: int, HW: int):
+    """AE3DConv.time_mix_conv + token-major -> NCHW (gcd_time_mix_unpack); w fp32 [C, C, 3]."""
+    _need_gpu(tok32, w, b, out_nchw)
+    assert out_nchw.is_contiguous() and out_nchw.dtype == torch.float32
+    assert w.is_contiguous() and w.dtype == torch.float32 and w.numel() == C * C * 3
+    check(_lib.load().gcd_time_mix_unpack(tok32.data_ptr(), _ld(tok32), w.data_ptr(), b.data_ptr(),
+                                          out_nchw.data_ptr(), C, N, T, HW, _stream()),
+          "gcd_time_mix_unpack")
+    return out_nchw
 
 
 def pack_input(x, concat, c_in, N: int, HW: int, out16, Cpad: int):

@@ -177,6 +177,22 @@ int gcd_attn_spatial_f16(const void* qkv, int64_t ld, const void* vt, int S_pad,
 int gcd_attn_temporal_f16(const void* qkv, int64_t ld, void* out, int64_t ldo, int clips, int T,
                           int HW, int heads, void* stream);
 
+/* ---- first-stage decoder (VideoDecoder) helpers ------------------------------------------------ */
+/* y16[r, :] = softmax(x[r, :]) for an fp32 score matrix [R, C] (C % 4 == 0, C <= 16384): the softmax
+ * of the VAE decoder's single-head mid attention (diffusionmodules/model.py:180-198, head dim = the
+ * 512 channels, so Q K^T and P V run on gcd_gemm_f16 with the 1/sqrt(C) scale in its epilogue).   */
+int gcd_softmax_rows_f16(const float* x, int64_t ldx, void* y16, int64_t ldy, int64_t R, int C,
+                         void* stream);
+/* fp16 [R, C] -> [C, R] (V -> V^T, the [N, K] operand of the P V GEMM).                           */
+int gcd_transpose_f16(const void* x, int64_t ldx, void* y, int64_t ldy, int R, int C, void* stream);
+/* AE3DConv.time_mix_conv (temporal_ae.py:84-107: Conv3d C -> C, kernel (3,1,1), zero padding in
+ * time, applied to the output of the last 3x3 conv) fused with the token-major -> NCHW change:
+ *   out[n][co][p] = b[co] + sum_{dt,ci} w[co][ci][dt] * in[((n + dt - 1)*HW + p)*ld + ci]
+ * over the frames of n's clip of T frames.  in: fp32 [N*HW, ld]; w: fp32 [C, C, 3] (the Conv3d weight
+ * with its two unit axes dropped); out: fp32 [N, C, HW]; C <= 4.                                   */
+int gcd_time_mix_unpack(const float* in, int64_t ld, const float* w, const float* b, float* out,
+                        int C, int N, int T, int HW, void* stream);
+
 /* ---- UNet ends, casts ----------------------------------------------------------------------- */
 /* NCHW fp32 -> token-major fp16, fusing the sampler-side glue in front of the first conv:
  *   out16[(n*HW + p)*Cpad + c] = x[n % nx][c][p] * c_in[n]      c < Cx       (denoiser.py:46-48,
