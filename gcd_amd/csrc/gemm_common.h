@@ -168,6 +168,111 @@ __device__ __forceinline__ void gcd_epilogue_64x160_ln(const GemmK& p, f32x16 (&
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pipelined epilogues for a FULL 64 x 160 wave tile (every row < M, every column < N).
+//
+// The generic epilogue further below issues one residual load, waits for it (s_waitcnt vmcnt(0),
+// which on gfx9-family hardware also waits for every earlier STORE: loads and stores share the
+// in-order vmcnt counter), stores, and repeats — the output may alias the residual, so the compiler
+// cannot hoist a load over the previous store.  That serialises 40 HBM round trips per wave and tile.
+// Here the residual vectors are fetched in batches of 4 (one 32 x 32 tile) that run D batches ahead
+// of their use, so the counted waits the compiler derives only cover stores issued D batches earlier
+// and 4-8 KB of loads per wave (32-64 KB per CU) stay in flight.  Aliasing stays legal: every element
+// is loaded by the lane that later stores it, before that store.
+//
+// lb: this wave's 160 per-column addends in LDS (bias + the rowvec row when it is uniform over the
+// tile), staged by the caller — bias loads would otherwise sit in vmcnt between the stores.
+// ------------------------------------------------------------------------------------------------
+// fp32 outputs, row-major.  tools/hbm_epi (the same read-modify-write without the GEMM,
+// 330 MB in place, 256 x 8 waves): accumulator-layout accesses (32 rows x 32 B per instruction) run
+// at 3.8 TB/s, row-contiguous ones (8 rows x 128 B) at 5.6 TB/s — the vector-memory path wants whole
+// 128-byte lines per instruction.  Each 32 x 32 accumulator tile is therefore transposed through a
+// wave-private LDS tile (`stage`, >= 4608 B): lane -> row 8 qq + (lane >> 3), channels 4 (lane & 7),
+// and the residual vectors are fetched in that layout, D tiles ahead.  sa / sr1 / sr2 are
+// wave-uniform here (the caller checked that one frame_alpha entry serves the whole tile).
+template <bool HAS_R1, bool HAS_R2>
+__device__ __forceinline__ void gcd_epi_f32_rows_full(const GemmK& p, f32x16 (&acc)[5][2], int m_base,
+                                                     int n_base, int lane, const float* lb, char* stage,
+                                                     float sa, float sr1, float sr2) {
+  constexpr int D = HAS_R2 ? 1 : 2;
+  const int l31 = lane & 31, hh = lane >> 5, rr = lane >> 3, cc = (lane & 7) * 4;
+  const int64_t col = n_base + cc;
+  float* const op = (float*)p.out + (int64_t)(m_base + rr) * p.ldo + col;
+  const float* const r1p = HAS_R1 ? p.R1 + (int64_t)(m_base + rr) * p.ldr1 + col : nullptr;
+  const float* const r2p = HAS_R2 ? p.R2 + (int64_t)(m_base + rr) * p.ldr2 + col : nullptr;
+  const int64_t so = 8 * p.ldo, s1 = 8 * p.ldr1, s2 = 8 * p.ldr2;
+  char* const wr = stage + l31 * GCD_EPI_ROW_F32 + hh * 16;
+  const char* const rd = stage + rr * GCD_EPI_ROW_F32 + cc * 4;
+  f32x4 q1[D][4], q2[D][4];
+  auto fetch = [&](int b, int slot) {   // tile b = (column block b >> 1, token half b & 1)
+    const int i = b >> 1, j = b & 1;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      if (HAS_R1) q1[slot][qq] = *(const f32x4*)(r1p + (4 * j + qq) * s1 + 32 * i);
+      if (HAS_R2) q2[slot][qq] = *(const f32x4*)(r2p + (4 * j + qq) * s2 + 32 * i);
+    }
+  };
+  if (HAS_R1 || HAS_R2) {
+#pragma unroll
+    for (int b = 0; b < D; ++b) fetch(b, b);
+  }
+#pragma unroll
+  for (int b = 0; b < 10; ++b) {
+    const int i = b >> 1, j = b & 1;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+      *(f32x4*)(wr + g * 32) = v;
+    }
+    const f32x4 bv = *(const f32x4*)(lb + 32 * i + cc);
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      f32x4 v = *(const f32x4*)(rd + qq * 8 * GCD_EPI_ROW_F32);
+      v = (v + bv) * sa;
+      if (HAS_R1) v += sr1 * q1[b % D][qq];
+      if (HAS_R2) v += sr2 * q2[b % D][qq];
+      *(f32x4*)(op + (4 * j + qq) * so + 32 * i) = v;
+    }
+    if ((HAS_R1 || HAS_R2) && b + D < 10) fetch(b + D, b % D);
+    __builtin_amdgcn_sched_barrier(0);   // keep the pipeline order (and the register budget) as written
+  }
+}
+
+// a * gelu(g) of a full wave tile (value / gate rows interleaved in 16s by packing.pack_geglu, so both
+// live in the same lane; lb as above).  The wave's 64 x 80 fp16 results go through its LDS stage
+// ([64][80] + 16 B row pad) and leave as 16-byte pieces of 160-byte row segments: 6.4 rows per store
+// instruction instead of 32 rows x 16 B straight from the accumulator layout, and half as many store
+// instructions (measured -3..-7 % per GEGLU launch, profiles/r01q_gemm_bench_rows.txt).
+__device__ __forceinline__ void gcd_epi_geglu_rows_full(const GemmK& p, f32x16 (&acc)[5][2], int m_base,
+                                                        int n_base, int lane, const float* lb, char* stage) {
+  const int l31 = lane & 31, hh = lane >> 5;
+  const float* lbl = lb + 4 * hh;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const f32x4 ba = *(const f32x4*)(lbl + 32 * i + 8 * g);
+        const f32x4 bg = *(const f32x4*)(lbl + 32 * i + 16 + 8 * g);
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = (f16)((acc[i][j][4 * g + e] + ba[e]) * gelu_fast(acc[i][j][8 + 4 * g + e] + bg[e]));
+        *(f16x4*)(stage + (32 * j + l31) * GCD_EPI_ROW_F16 + (16 * i + 8 * g + 4 * hh) * 2) = o;
+      }
+  f16* const outp = (f16*)p.out + (int64_t)m_base * p.ldo + (n_base >> 1);
+#pragma unroll
+  for (int it = 0; it < 10; ++it) {
+    const int tt = it * 64 + lane;
+    const int row = tt / 10, ch = tt - row * 10;
+    const f16x8 v = *(const f16x8*)(stage + row * GCD_EPI_ROW_F16 + ch * 16);
+    *(f16x8*)(outp + (int64_t)row * p.ldo + ch * 8) = v;
+  }
+}
+
 template <int EV = 0>
 __device__ __forceinline__ void gcd_epilogue_64x160(const GemmK& p, f32x16 (&acc)[5][2], int m_base,
                                                     int n_base, int lane, char* stage) {

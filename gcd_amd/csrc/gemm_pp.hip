@@ -39,7 +39,8 @@ constexpr int PP_BM = 256, PP_BN = 320;
 constexpr int PP_A_BYTES = PP_BM * 64;                  // A sub-tile: 256 rows x 32 fp16
 constexpr int PP_W_BYTES = PP_BN * 64;                  // W sub-tile: 320 rows x 32 fp16
 constexpr int PP_SLOT = PP_A_BYTES + PP_W_BYTES;        // 36864
-constexpr int PP_SMEM = 4 * PP_SLOT;                    // 147456
+constexpr int PP_SMEM = 4 * PP_SLOT;                    // 147456: the ring
+constexpr int PP_SMEM_LAUNCH = PP_SMEM + 320 * 4;        // + the epilogue's per-column addends
 constexpr int PP_GROUP_M = 4;
 
 #define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -72,58 +73,24 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
     L_end = PERSIST ? start + q + (xcd < r ? 1 : 0) : L + 1;
     L_step = PERSIST ? (int)(gridDim.x >> 3) : 1;
   }
-  for (; L < L_end; L += L_step) {
-  int tile_m, tile_n;
-  const int kz = (VAR & 16384) ? L % p.splitk : 0;          // split-K: K slice of this workgroup
-  {
-    const int Lt = (VAR & 16384) ? L / p.splitk : L;
-    const int per_group = PP_GROUP_M * p.tiles_n;
-    const int gi = Lt / per_group;
-    const int rem = Lt - gi * per_group;
-    const int m_first = gi * PP_GROUP_M;
-    const int gm = min(PP_GROUP_M, p.tiles_m - m_first);
-    tile_n = rem / gm;
-    tile_m = m_first + rem - tile_n * gm;
-  }
-  const int m0 = tile_m * PP_BM, n0 = tile_n * PP_BN;
-  // 32-deep sub-tiles of this workgroup: all of K, or slice kz of it
-  int s_begin = 0, S = p.K >> 5;
-  if (VAR & 16384) {
-    const int per = (S + p.splitk - 1) / p.splitk;
-    s_begin = kz * per;
-    S = min(per, S - s_begin);
-  }
-
-  // ---- DMA bookkeeping: a piece = 16 rows x 64 B = one global_load_lds_dwordx4 of a wave ----
+  // ---- per-tile state (set_tile) ----
+  int m0 = 0, n0 = 0, kz = 0, s_begin = 0, S = p.K >> 5;
   const int lrow = lane >> 2;
   const int lc16 = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;   // logical 16-B chunk this lane fetches
+  // DMA bookkeeping: a piece = 16 rows x 64 B = one global_load_lds_dwordx4 of a wave.
   // A: wave w loads pieces 2w, 2w+1 (tile rows 32w .. 32w+31)
-  const char* a_base[2];
-  int a_inc[2];              // bytes per channel step: 2, or 0 when the tap reads the zero page
-  int a_y[2], a_x[2];
-  int64_t a_fb[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int m = m0 + 32 * wave + 16 * i + lrow;
-    m = m < p.M ? m : p.M - 1;
-    a_y[i] = a_x[i] = 0;
-    a_fb[i] = 0;
-    a_base[i] = nullptr;
-    a_inc[i] = 2;
-    if (MODE == GCD_GEMM_PLAIN) {
-      a_base[i] = (const char*)p.A + (int64_t)m * p.lda * 2 + lc16;
-    } else if (MODE == GCD_GEMM_CONV3X3) {
-      const int hw = p.Ho * p.Wo;
-      const int n = m / hw;
-      const int rem = m - n * hw;
-      a_y[i] = rem / p.Wo;
-      a_x[i] = rem - a_y[i] * p.Wo;
-      a_fb[i] = (int64_t)n * p.Hi * p.Wi;
-    } else {
-      a_y[i] = (m / p.HW) % p.T;
-      a_fb[i] = m;
-    }
-  }
+  const char* a_base[2] = {nullptr, nullptr};
+  int a_inc[2] = {2, 2};     // bytes per channel step: 2, or 0 when the tap reads the zero page
+  int a_y[2] = {0, 0}, a_x[2] = {0, 0};
+  int64_t a_fb[2] = {0, 0};
+  int a_tap = 0, a_c0 = 0;   // K position of the next A issue (conv modes), block-uniform
+  // W: group 0 wave w loads pieces 3w .. 3w+2, group 1 wave w' loads 12+2w', 13+2w'
+  const int w_first = grp == 0 ? 3 * wave : 12 + 2 * (wave - 4);
+  const char* w_base[3] = {nullptr, nullptr, nullptr};
+  float* const lds_bias = (float*)(smem + PP_SMEM);   // 320 staged per-column addends
+  bool lds_bias_ok = false;   // staged addends cover bias (+ rowvec) of the whole tile
+  bool alpha_uni = true;      // one frame_alpha entry serves the whole tile
+
   auto set_tap = [&](int tap) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -154,9 +121,81 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
       }
     }
   };
-  // K position of the next A issue (conv modes), block-uniform
-  int a_tap = (MODE != GCD_GEMM_PLAIN) ? (s_begin * 32) / p.Cin : 0;
-  int a_c0 = (MODE != GCD_GEMM_PLAIN) ? s_begin * 32 - a_tap * p.Cin : 0;
+  // Tile Lx of the linear order -> (m0, n0), DMA source addresses, staged epilogue addends.
+  auto set_tile = [&](int Lx) {
+    int tile_m, tile_n;
+    kz = (VAR & 16384) ? Lx % p.splitk : 0;          // split-K: K slice of this workgroup
+    {
+      const int Lt = (VAR & 16384) ? Lx / p.splitk : Lx;
+      const int per_group = PP_GROUP_M * p.tiles_n;
+      const int gi = Lt / per_group;
+      const int rem = Lt - gi * per_group;
+      const int m_first = gi * PP_GROUP_M;
+      const int gm = min(PP_GROUP_M, p.tiles_m - m_first);
+      tile_n = rem / gm;
+      tile_m = m_first + rem - tile_n * gm;
+    }
+    m0 = tile_m * PP_BM;
+    n0 = tile_n * PP_BN;
+    // 32-deep sub-tiles of this workgroup: all of K, or slice kz of it
+    s_begin = 0;
+    S = p.K >> 5;
+    if (VAR & 16384) {
+      const int per = (S + p.splitk - 1) / p.splitk;
+      s_begin = kz * per;
+      S = min(per, S - s_begin);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int m = m0 + 32 * wave + 16 * i + lrow;
+      m = m < p.M ? m : p.M - 1;
+      a_y[i] = a_x[i] = 0;
+      a_fb[i] = 0;
+      a_base[i] = nullptr;
+      a_inc[i] = 2;
+      if (MODE == GCD_GEMM_PLAIN) {
+        a_base[i] = (const char*)p.A + (int64_t)m * p.lda * 2 + lc16;
+      } else if (MODE == GCD_GEMM_CONV3X3) {
+        const int hw = p.Ho * p.Wo;
+        const int n = m / hw;
+        const int rem = m - n * hw;
+        a_y[i] = rem / p.Wo;
+        a_x[i] = rem - a_y[i] * p.Wo;
+        a_fb[i] = (int64_t)n * p.Hi * p.Wi;
+      } else {
+        a_y[i] = (m / p.HW) % p.T;
+        a_fb[i] = m;
+      }
+    }
+    a_tap = (MODE != GCD_GEMM_PLAIN) ? (s_begin * 32) / p.Cin : 0;
+    a_c0 = (MODE != GCD_GEMM_PLAIN) ? s_begin * 32 - a_tap * p.Cin : 0;
+    if (MODE != GCD_GEMM_PLAIN) set_tap(a_tap);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      int n = n0 + 16 * (w_first + j) + lrow;
+      n = n < p.N ? n : p.N - 1;
+      w_base[j] = (const char*)p.W + (int64_t)n * p.K * 2 + lc16;
+    }
+    // epilogue addends of this tile's 320 columns: bias, plus the rowvec row when one row serves
+    // the whole tile (always at the 72x128 / 36x64 levels: 9216 and 2304 rows per frame)
+    if (!(VAR & (16384 | 8192))) {
+      const int m_last = min(m0 + PP_BM, p.M) - 1;
+      const bool rv_uni = !p.rowvec || (m0 / p.rows_per_vec == m_last / p.rows_per_vec);
+      lds_bias_ok = rv_uni;
+      alpha_uni = !p.frame_alpha || (m0 / p.rows_per_alpha == m_last / p.rows_per_alpha);
+      if (t < 80) {
+        const int n = n0 + 4 * t;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < p.N) {
+          if (p.bias) v = *(const f32x4*)(p.bias + n);
+          if (p.rowvec && rv_uni)
+            v += *(const f32x4*)(p.rowvec + (int64_t)(m0 / p.rows_per_vec) * p.ld_rowvec + n);
+        }
+        *(f32x4*)(lds_bias + 4 * t) = v;
+      }
+    }
+  };
+
   bool dma_on = true;
   auto issue_A = [&](int sigma) {
     if (sigma < S && dma_on) {
@@ -178,19 +217,31 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
       }
     }
   };
-  // W: group 0 wave w loads pieces 3w .. 3w+2, group 1 wave w' loads 12+2w', 13+2w'
-  const int w_first = grp == 0 ? 3 * wave : 12 + 2 * (wave - 4);
-  const char* w_base[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    int n = n0 + 16 * (w_first + j) + lrow;
-    n = n < p.N ? n : p.N - 1;
-    w_base[j] = (const char*)p.W + (int64_t)n * p.K * 2 + lc16;
-  }
   auto issue_W = [&](int j, int sigma) {
     if (sigma < S && dma_on)
       glds16(w_base[j] + (s_begin + sigma) * 64,
              smem + (sigma & 3) * PP_SLOT + PP_A_BYTES + (w_first + j) * 1024);
+  };
+  // prologue in steady-state order: sub-tiles 0, 1 and (group 0: the first part of) 2
+  auto issue_prologue = [&]() {
+    if (grp == 0) {
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg) {
+        issue_A(sg);
+        issue_W(0, sg);
+        issue_W(1, sg);
+        issue_W(2, sg);
+      }
+      issue_A(2);
+      issue_W(0, 2);
+    } else {
+#pragma unroll
+      for (int sg = 0; sg < 3; ++sg) {
+        issue_A(sg);
+        issue_W(0, sg);
+        issue_W(1, sg);
+      }
+    }
   };
 
   // ---- fragment read addresses (per lane, within a slot) ----
@@ -202,6 +253,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
     rdA[ks] = (64 * wm + l31) * 64 + ch;
     rdW[ks] = PP_A_BYTES + (160 * wn + l31) * 64 + ch;
   }
+
+  for (; L < L_end; L += L_step) {
+  set_tile(L);
+  issue_prologue();
 
   f32x16 acc[5][2];
 #pragma unroll
@@ -244,26 +299,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
     __builtin_amdgcn_sched_barrier(0);                             \
   } while (0)
 
-  // ---- prologue: sub-tiles 0, 1 and (group 0: the first part of) 2, in steady-state order ----
-  if (MODE != GCD_GEMM_PLAIN) set_tap(a_tap);
-  if (grp == 0) {
-#pragma unroll
-    for (int sg = 0; sg < 2; ++sg) {
-      issue_A(sg);
-      issue_W(0, sg);
-      issue_W(1, sg);
-      issue_W(2, sg);
-    }
-    issue_A(2);
-    issue_W(0, 2);
-  } else {
-#pragma unroll
-    for (int sg = 0; sg < 3; ++sg) {
-      issue_A(sg);
-      issue_W(0, sg);
-      issue_W(1, sg);
-    }
-  }
   if (S > 2) {
     PP_VMCNT(8);   // everything of sub-tile 0 has landed (8 newer pieces may still fly)
   } else {
@@ -322,17 +357,44 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
     }
   }
 
-  // ---- epilogue (gemm_common.h): LDS-transposed, 128-byte-row global accesses.  Every wave is
-  //      past its last fragment read of the ring (see the barrier structure above). ----
+  // ---- epilogue (gemm_common.h) ----
+  // (opaque copies: keeps the compiler from hoisting the epilogue's address arithmetic above the K
+  //  loop, where it would cost registers the loop does not have)
+  int wm_base = m0 + 64 * wm, wn_base = n0 + 160 * wn, elane = lane;
+  asm volatile("" : "+s"(wm_base), "+s"(wn_base), "+v"(elane));
   if constexpr ((VAR & 16384) != 0) {   // split-K: raw fp32 partial sums of this K slice
     GemmK q = p;
     q.out = (float*)p.out + (int64_t)kz * p.split_stride;
-    gcd_epilogue_64x160<8>(q, acc, m0 + 64 * wm, n0 + 160 * wn, lane, smem);
-  } else if constexpr ((VAR & 8192) != 0)   // own instantiation: fused LayerNorm (N == 320)
-    gcd_epilogue_64x160_ln(p, acc, m0 + 64 * wm, n0 + 160 * wn, lane, wm, wn, (float*)smem);
-  else
-    gcd_epilogue_64x160<(((VAR >> 6) & 31) | ((VAR & 32768) ? 32 : 0))>(p, acc, m0 + 64 * wm, n0 + 160 * wn, lane,
-                                           smem + wave * GCD_EPI_STAGE_BYTES);
+    gcd_epilogue_64x160<8>(q, acc, wm_base, wn_base, elane, smem);
+  } else if constexpr ((VAR & 8192) != 0) {   // own instantiation: fused LayerNorm (N == 320)
+    gcd_epilogue_64x160_ln(p, acc, wm_base, wn_base, elane, wm, wn, (float*)smem);
+  } else {
+    constexpr int EV = ((VAR >> 6) & 31) | ((VAR & 32768) ? 32 : 0);
+    const bool full = wm_base + 64 <= p.M && wn_base + 160 <= p.N && lds_bias_ok;
+    const float* lb = lds_bias + 160 * wn;
+    if (EV == 0 && full && p.out_kind == GCD_OUT_GEGLU && (p.ldo & 7) == 0) {
+      gcd_epi_geglu_rows_full(p, acc, wm_base, wn_base, elane, lb, smem + wave * GCD_EPI_STAGE_BYTES);
+    } else if (EV == 0 && full && alpha_uni && p.out_kind == GCD_OUT_F32) {
+      float sa = p.s_acc, sr1 = p.s_r1, sr2 = p.s_r2;
+      if (p.frame_alpha) {
+        const float al = p.frame_alpha[m0 / p.rows_per_alpha];
+        sa = 1.0f - al;
+        sr2 = al;
+        if (p.r1_blend) sr1 *= 1.0f - al;
+      }
+      char* stage = smem + wave * GCD_EPI_STAGE_BYTES;
+      if (p.R2) {
+        p.R1 ? gcd_epi_f32_rows_full<true, true>(p, acc, wm_base, wn_base, elane, lb, stage, sa, sr1, sr2)
+                   : gcd_epi_f32_rows_full<false, true>(p, acc, wm_base, wn_base, elane, lb, stage, sa, sr1, sr2);
+      } else {
+        p.R1 ? gcd_epi_f32_rows_full<true, false>(p, acc, wm_base, wn_base, elane, lb, stage, sa, sr1, sr2)
+                   : gcd_epi_f32_rows_full<false, false>(p, acc, wm_base, wn_base, elane, lb, stage, sa, sr1, sr2);
+      }
+    } else {
+      // ragged edge tiles, fp16 outputs, a rowvec / alpha that changes inside the tile
+      gcd_epilogue_64x160<EV>(p, acc, wm_base, wn_base, elane, smem + wave * GCD_EPI_STAGE_BYTES);
+    }
+  }
   if (PERSIST) __syncthreads();   // epilogue LDS use vs the next tile's prologue DMA
   }   // tile loop
 }
@@ -343,7 +405,7 @@ int launch_pp(const GemmK& k, hipStream_t s) {
   auto fn = gemm_pp_kernel<MODE, VAR>;
   if (!attr_set) {
     GCD_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      PP_SMEM));
+                                      PP_SMEM_LAUNCH));
     attr_set = true;
   }
   GemmK kk = k;
@@ -352,7 +414,7 @@ int launch_pp(const GemmK& k, hipStream_t s) {
   int64_t nblk = (int64_t)kk.tiles_m * kk.tiles_n;
   GCD_CHECK_ARG(nblk > 0 && nblk < (1ll << 31), "gcd_gemm_f16 (pp): bad grid %lld", (long long)nblk);
   if ((VAR & 2048) && nblk > 256) nblk = 256;   // persistent: one workgroup per CU, 32 per XCD
-  hipLaunchKernelGGL(fn, dim3((unsigned)nblk), dim3(512), PP_SMEM, s, kk);
+  hipLaunchKernelGGL(fn, dim3((unsigned)nblk), dim3(512), PP_SMEM_LAUNCH, s, kk);
   GCD_CHECK_LAUNCH();
   return 0;
 }
@@ -400,7 +462,7 @@ int launch_pp_splitk(const GemmK& k, int splitk, float* ws, hipStream_t s) {
   auto fn = gemm_pp_kernel<MODE, 16384>;
   if (!attr_set) {
     GCD_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      PP_SMEM));
+                                      PP_SMEM_LAUNCH));
     attr_set = true;
   }
   GemmK kk = k;
@@ -416,7 +478,7 @@ int launch_pp_splitk(const GemmK& k, int splitk, float* ws, hipStream_t s) {
   kk.s_acc = 1.0f;
   kk.ln_out = nullptr;
   const int64_t nblk = (int64_t)kk.tiles_m * kk.tiles_n * splitk;
-  hipLaunchKernelGGL(fn, dim3((unsigned)nblk), dim3(512), PP_SMEM, s, kk);
+  hipLaunchKernelGGL(fn, dim3((unsigned)nblk), dim3(512), PP_SMEM_LAUNCH, s, kk);
   GCD_CHECK_LAUNCH();
   GemmK kr = k;
   kr.split_stride = kk.split_stride;
