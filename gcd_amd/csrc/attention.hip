@@ -275,6 +275,247 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Spatial flash attention, 64 queries per wave (GCD_TUNE_ATTN_IMPL = 2 / automatic for S >= 1024).
+//
+// Same arithmetic as attn_spatial_kernel, twice the queries per wave: the kernel above spends more
+// issue slots on LDS fragment reads, LDS-DMA pieces, the barrier and the loop skeleton than on MFMA
+// (profiles/r01_attention_ablation.txt), and all of those are per wave and tile, not per score — a
+// wave that owns two 32-query blocks reads each K / V^T fragment once for both, issues the same four
+// DMA pieces per tile for twice the scores and passes half as many barriers per score.
+// Register budget (256 at 2 waves per SIMD): O^T of both query blocks is 64 registers, Q 32, the
+// scores of a tile 64.  The 16-register -m_ref and denominator blocks of the kernel above do not fit:
+//   * the reference max is subtracted by a FIFTH k-step instead:  S^T += Kones (keys x 16, column 0
+//     = 1)  x  Qm (16 x queries, row 0 = -m_ref), with m_ref kept exactly representable in fp16 (it
+//     is only a reference point: it moves by the rounded-up tile excess, and O / the denominator are
+//     rescaled by exactly the amount it moved);
+//   * the denominator is summed from the fp16 P values the P V product consumes (v_dot2_f32_f16, two
+//     per instruction) — and doubles as the overflow check: all p >= 0, so a per-lane tile sum <= 128
+//     proves every p <= 2^7.  Only when some lane's sum is larger (or on the first tile, which defines
+//     the reference) is the tile maximum computed at all; the steady state has no max pass.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+template <bool PRESCALED>
+__global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const f16* __restrict__ qkv, int64_t ld,
+                                                                const f16* __restrict__ vt, int S_pad,
+                                                                f16* __restrict__ out, int64_t ldo,
+                                                                int S, int heads, int nqb,
+                                                                float c /* scale * log2(e) */) {
+  __shared__ __attribute__((aligned(16))) char smem[3 * 16384];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  int qb, head, frame;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    qb = L % nqb;
+    const int fh = L / nqb;
+    head = fh % heads;
+    frame = fh / heads;
+  }
+  const int C = heads * 64;
+  const int q0 = qb * 256 + wave * 64;
+
+  // Q^T fragments (B operand) of the two query blocks: query 32 b + l31, d = 16 ks + 8 half + j
+  f16x8 qf[2][4];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    int qi = q0 + 32 * b + l31;
+    qi = qi < S ? qi : S - 1;
+    const f16* qp = qkv + ((int64_t)frame * S + qi) * ld + head * 64 + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[b][ks] = *(const f16x8*)(qp + ks * 16);
+  }
+  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  f16x8 kones = zero8;            // A operand of the fifth k-step: k = 0 column of ones
+  if (half == 0) kones[0] = (f16)1.f;
+  f16x8 qm[2] = {zero8, zero8};   // B operand of the fifth k-step: row k = 0 holds -m_ref
+  float mref[2] = {0.f, 0.f};
+  float lsum[2] = {0.f, 0.f};     // this lane's share of the softmax denominators
+
+  const int prow = t >> 3;
+  const int cl = (t & 7) ^ ((prow >> 1) & 7);
+  const f16* kbase = qkv + (int64_t)frame * S * ld + C + head * 64 + cl * 8;
+  const f16* vbase = vt + (((int64_t)frame * heads + head) * 64) * S_pad + cl * 8;
+  const int ntiles = (S + 63) >> 6;
+  auto stage = [&](int kt) {
+    if (kt < ntiles) {
+      const int kv0 = kt << 6;
+      char* Ks = smem + (kt % 3) * 16384;
+      char* Vs = Ks + 8192;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = prow + 32 * i;
+        int key = kv0 + row;
+        key = key < S ? key : S - 1;
+        glds16(kbase + (int64_t)key * ld, Ks + (i * 256 + wave * 64) * 16);
+        glds16(vbase + (int64_t)row * S_pad + kv0, Vs + (i * 256 + wave * 64) * 16);
+      }
+    }
+  };
+
+  f32x16 o0[2], o1[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[b][r] = o1[b][r] = 0.f;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const f16x2 one2 = {(f16)1.f, (f16)1.f};
+  int foff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) foff[ks] = lds_tile_off(l31, 2 * ks + half);
+
+  stage(0);
+  stage(1);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    if (kt + 1 < ntiles) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    stage(kt + 2);
+    const char* Ks = smem + (kt % 3) * 16384;
+    const char* Vs = Ks + 8192;
+
+    // ---- S^T - m_ref for both query blocks; K fragments of one 32-key half at a time ----
+    f32x16 sc[2][2];   // [query block][key half]
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f16x8 kf[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const f16x8*)(Ks + foff[ks] + 4096 * kb);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        sc[b][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kones, qm[b], zero16, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          sc[b][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[b][ks], sc[b][kb], 0, 0, 0);
+      }
+    }
+    f16x8 pfb[2][4];  // pfb[b][c2] = P^T fragment (B operand) of query block b, keys 16 c2 .. 16 c2 + 15
+    f16x8 vf[8];      // vf[2*c2 + dt]: d rows 32 dt + l31, keys 16 c2 + {0-3, 8-11} + 4 half
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      f32x16& s0 = sc[b][0];
+      f32x16& s1 = sc[b][1];
+      if (!PRESCALED) {
+        // scores arrive in natural units with -m_ref (exp2 units) already added
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s0[r] = fmaf(s0[r] + mref[b], c, -mref[b]);
+          s1[r] = fmaf(s1[r] + mref[b], c, -mref[b]);
+        }
+      }
+      // register r of a key half holds key (r&3) + 8*(r>>2) + 4*half
+      if ((kt << 6) + 64 > S) {
+        const int kb0 = (kt << 6) + 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb0 + (r & 3) + 8 * (r >> 2);
+          if (key >= S) s0[r] = -INFINITY;
+          if (key + 32 >= S) s1[r] = -INFINITY;
+        }
+      }
+      f16x8 (&pf)[4] = pfb[b];
+      float lt;
+      auto exponentiate = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          pf[r >> 3][r & 7] = (f16)__builtin_amdgcn_exp2f(s0[r]);
+          pf[2 + (r >> 3)][r & 7] = (f16)__builtin_amdgcn_exp2f(s1[r]);
+        }
+        lt = 0.f;
+#pragma unroll
+        for (int c2 = 0; c2 < 4; ++c2)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            lt = __builtin_amdgcn_fdot2(f16x2{pf[c2][2 * jj], pf[c2][2 * jj + 1]}, one2, lt, false);
+      };
+      exponentiate();
+      // ---- rare path: move the reference (always on the first tile, which defines it) ----
+      if (kt == 0 || __any(!(lt <= 128.f))) {
+        float mx = max3_f(s0[0], s1[0], s0[1]);
+        mx = max3_f(mx, s1[1], s0[2]);
+#pragma unroll
+        for (int r = 2; r < 15; ++r) mx = max3_f(mx, s1[r], s0[r + 1]);
+        mx = fmaxf(mx, s1[15]);
+        {
+          const unsigned mu = __float_as_uint(mx);
+          const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+          mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        const bool mv = kt == 0 || mx > 7.0f;
+        // new reference = fp16-exact value at or above the tile max; delta = how far it really moved
+        const float want = mv ? mref[b] + ceilf(mx) : mref[b];
+        const float nref = (float)(f16)want;
+        const float delta = nref - mref[b];
+        const float alpha = kt == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);   // O, l still 0 on tile 0
+        mref[b] = nref;
+        if (half == 0) qm[b][0] = (f16)(-nref);
+        lsum[b] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s0[r] -= delta;
+          s1[r] -= delta;
+          o0[b][r] *= alpha;
+          o1[b][r] *= alpha;
+        }
+        exponentiate();
+      }
+      lsum[b] += lt;
+      if (b == 0) {
+        // V^T fragments: issued between the two softmax passes, their latency hides under the second
+#pragma unroll
+        for (int c2 = 0; c2 < 4; ++c2) {
+          vf[2 * c2] = *(const f16x8*)(Vs + foff[c2]);
+          vf[2 * c2 + 1] = *(const f16x8*)(Vs + foff[c2] + 4096);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- O^T += V^T P^T for both query blocks ----
+#pragma unroll
+    for (int c2 = 0; c2 < 4; ++c2)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        o0[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[2 * c2], pfb[b][c2], o0[b], 0, 0, 0);
+        o1[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[2 * c2 + 1], pfb[b][c2], o1[b], 0, 0, 0);
+      }
+  }
+
+  // ---- normalise and store: o{0,1}[r] is O[query l31][d = 32 dt + (r&3) + 8 (r>>2) + 4 half] ----
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    float l = lsum[b];   // the two halves of a query column hold disjoint keys
+    {
+      const unsigned lu = __float_as_uint(l);
+      const auto sw = __builtin_amdgcn_permlane32_swap(lu, lu, false, false);
+      l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    const float inv = 1.0f / l;
+    const int qi = q0 + 32 * b + l31;
+    if (qi < S) {
+      f16* op = out + ((int64_t)frame * S + qi) * ldo + head * 64 + 4 * half;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f16x4 v0, v1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v0[e] = (f16)(o0[b][4 * g + e] * inv);
+          v1[e] = (f16)(o1[b][4 * g + e] * inv);
+        }
+        *(f16x4*)(op + 8 * g) = v0;
+        *(f16x4*)(op + 32 + 8 * g) = v1;
+      }
+    }
+  }
+}
+
 extern "C" int gcd_attn_spatial_f16(const void* qkv, int64_t ld, const void* vt, int S_pad,
                                     void* out, int64_t ldo, int frames, int S, int heads,
                                     int q_prescaled, void* stream) {
@@ -283,13 +524,26 @@ extern "C" int gcd_attn_spatial_f16(const void* qkv, int64_t ld, const void* vt,
   GCD_CHECK_ARG(S_pad % 64 == 0 && S_pad >= S, "gcd_attn_spatial_f16: S_pad=%d for S=%d", S_pad, S);
   GCD_CHECK_ARG(ld % 8 == 0 && ld >= 3 * heads * 64 && ldo % 4 == 0 && ldo >= heads * 64,
                 "gcd_attn_spatial_f16: ld=%lld ldo=%lld", (long long)ld, (long long)ldo);
-  const int nqb = (S + 127) / 128;
+  const float c = 0.125f * LOG2E_F;  // head dim 64 -> scale 1/8, in exp2 units
+  hipStream_t st = (hipStream_t)stream;
+  // 64 queries per wave (256 per workgroup) unless the frame is too small to fill such blocks
+  const int impl = gcd_tune_get(GCD_TUNE_ATTN_IMPL);
+  // (measured: 72x128 tokens 4245 -> 3483 us, 36x64 553 -> 513 us; 18x32 = 576 tokens would waste a
+  //  quarter of its 256-query blocks and runs 92 vs 109 us on the 128-query kernel)
+  const bool wide = impl == 2 || (impl != 1 && S >= 1024);
+  const int qpb = wide ? 256 : 128;
+  const int nqb = (S + qpb - 1) / qpb;
   const int64_t nblk = (int64_t)nqb * heads * frames;
   GCD_CHECK_ARG(nblk < (1ll << 31), "gcd_attn_spatial_f16: grid too large");
-  const float c = 0.125f * LOG2E_F;  // head dim 64 -> scale 1/8, in exp2 units
   const dim3 grid((unsigned)nblk), block(256);
-  hipStream_t st = (hipStream_t)stream;
-  if (q_prescaled)
+  if (wide) {
+    if (q_prescaled)
+      hipLaunchKernelGGL(attn_spatial64_kernel<true>, grid, block, 0, st, (const f16*)qkv, ld,
+                         (const f16*)vt, S_pad, (f16*)out, ldo, S, heads, nqb, c);
+    else
+      hipLaunchKernelGGL(attn_spatial64_kernel<false>, grid, block, 0, st, (const f16*)qkv, ld,
+                         (const f16*)vt, S_pad, (f16*)out, ldo, S, heads, nqb, c);
+  } else if (q_prescaled)
     hipLaunchKernelGGL(attn_spatial_kernel<true>, grid, block, 0, st, (const f16*)qkv, ld,
                        (const f16*)vt, S_pad, (f16*)out, ldo, S, heads, nqb, c);
   else

@@ -168,40 +168,51 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
     sh[c] = beta[c] - mean * a;
   }
   __syncthreads();
-  const int cv8 = C >> 3;  // 8-channel vectors per row
+  // One float4 (4 channels) per lane and access: a wave's load covers 1 KB of one row and its fp16
+  // store 512 B — whole 128-byte lines per instruction (8 channels per lane left every load
+  // instruction with half-used lines).  Two vectors in flight per thread.
+  const int cv4 = C >> 2;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk;
   int64_t nrows = rows_per_inst - r0;
   if (nrows > rows_per_chunk) nrows = rows_per_chunk;
   const int64_t base = (int64_t)inst * rows_per_inst + r0;
-  const int64_t total = nrows * cv8;
-  for (int64_t idx = t; idx < total; idx += 256) {
-    const int64_t r = idx / cv8;
-    const int c = (int)(idx - r * cv8) * 8;
-    const float* src = (c < C1) ? x1 + (base + r) * ld1 + c : x2 + (base + r) * ld2 + (c - C1);
-    const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
-    const f32x4 a0 = *(const f32x4*)(sc + c), a1 = *(const f32x4*)(sc + c + 4);
-    const f32x4 b0 = *(const f32x4*)(sh + c), b1 = *(const f32x4*)(sh + c + 4);
-    f16x8 o;
+  const int64_t total = nrows * cv4;
+  auto src_of = [&](int64_t idx, int64_t& r, int& c) -> const float* {
+    r = idx / cv4;
+    c = (int)(idx - r * cv4) * 4;
+    return (c < C1) ? x1 + (base + r) * ld1 + c : x2 + (base + r) * ld2 + (c - C1);
+  };
+  auto emit = [&](const f32x4 v, int64_t r, int c) {
+    const f32x4 a = *(const f32x4*)(sc + c), b = *(const f32x4*)(sh + c);
+    f16x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float u0 = v0[e] * a0[e] + b0[e], u1 = v1[e] * a1[e] + b1[e];
-      if (silu) {
-        u0 = silu_f(u0);
-        u1 = silu_f(u1);
-      }
-      o[e] = (f16)u0;
-      o[e + 4] = (f16)u1;
+      float u = v[e] * a[e] + b[e];
+      if (silu) u = silu_f(u);
+      o[e] = (f16)u;
     }
-    *(f16x8*)(y + (base + r) * ldy + c) = o;
+    *(f16x4*)(y + (base + r) * ldy + c) = o;
     if (raw) {
-      f16x8 q;
+      f16x4 q;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        q[e] = (f16)v0[e];
-        q[e + 4] = (f16)v1[e];
-      }
-      *(f16x8*)(raw + (base + r) * ldraw + c) = q;
+      for (int e = 0; e < 4; ++e) q[e] = (f16)v[e];
+      *(f16x4*)(raw + (base + r) * ldraw + c) = q;
     }
+  };
+  int64_t idx = t;
+  for (; idx + 256 < total; idx += 512) {
+    int64_t ra, rb;
+    int ca, cb;
+    const f32x4 va = *(const f32x4*)src_of(idx, ra, ca);
+    const f32x4 vb = *(const f32x4*)src_of(idx + 256, rb, cb);
+    emit(va, ra, ca);
+    emit(vb, rb, cb);
+  }
+  if (idx < total) {
+    int64_t ra;
+    int ca;
+    const f32x4 va = *(const f32x4*)src_of(idx, ra, ca);
+    emit(va, ra, ca);
   }
 }
 

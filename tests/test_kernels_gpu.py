@@ -385,9 +385,18 @@ def test_layernorm(gpu, M, C):
 
 
 # ------------------------------------------------------------------------------------- attention
+@pytest.fixture(params=[0, 1, 2], ids=["attn-auto", "attn-q32", "attn-q64"])
+def attn_impl(request, gpu):
+    """Both spatial-attention kernels (32 / 64 queries per wave) over the same cases."""
+    from gcd_amd import ops
+    ops.tune_set(ops.TUNE_ATTN_IMPL, request.param)
+    yield request.param
+    ops.tune_set(ops.TUNE_ATTN_IMPL, 0)
+
+
 @pytest.mark.parametrize("frames,S,heads", [(2, 4, 1), (2, 16, 2), (1, 64, 2), (2, 100, 3),
-                                            (2, 144, 2), (1, 200, 5), (2, 576, 2), (1, 1300, 1)])
-def test_attention_spatial(gpu, frames, S, heads):
+                                            (2, 144, 2), (1, 200, 5), (2, 576, 2), (1, 1300, 1), (2, 2304, 1)])
+def test_attention_spatial(gpu, attn_impl, frames, S, heads):
     from gcd_amd import ops
     g = _gen(10)
     C = heads * 64
@@ -426,7 +435,7 @@ def test_attention_spatial(gpu, frames, S, heads):
     assert e < 1.5e-3, f"spatial attention (prescaled q) S={S}: rel-L2 {e:.3e}"
 
 
-def test_attention_spatial_reference_shift(gpu):
+def test_attention_spatial_reference_shift(gpu, attn_impl):
     """Scores that drift up and down by far more than the lazy-rescale threshold, a first tile whose
     scores are hugely negative, and a late outlier key: every branch of the reference-max logic."""
     from gcd_amd import ops

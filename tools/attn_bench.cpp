@@ -86,7 +86,8 @@ int main(int argc, char** argv) {
       std::vector<float> t;
       for (int it = 0; it < iters + 1; ++it) {
         CK(hipEventRecord(e0, st));
-        if (gcd_attn_spatial_f16(qkv, 3 * C, vt, S_pad, dst, C, s.frames, s.S, s.heads, impls[v] == 1 ? 0 : 1, st)) { fprintf(stderr, "%s\n", gcd_last_error()); return 1; }
+        // timed: the product form (q pre-scaled by log2(e)/8 when W_q was packed); same work per score
+        if (gcd_attn_spatial_f16(qkv, 3 * C, vt, S_pad, dst, C, s.frames, s.S, s.heads, 1, st)) { fprintf(stderr, "%s\n", gcd_last_error()); return 1; }
         CK(hipEventRecord(e1, st));
         CK(hipEventSynchronize(e1));
         float ms;
