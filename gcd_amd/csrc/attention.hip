@@ -282,7 +282,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
 // issue slots on LDS fragment reads, LDS-DMA pieces, the barrier and the loop skeleton than on MFMA
 // (profiles/r01_attention_ablation.txt), and all of those are per wave and tile, not per score — a
 // wave that owns two 32-query blocks reads each K / V^T fragment once for both, issues the same four
-// DMA pieces per tile for twice the scores and passes half as many barriers per score.
+// DMA pieces per tile for twice the scores and passes half as many barriers per score.  (Eight such
+// waves per workgroup — 512 queries, half the DMA pieces per wave again — measured slower: 3484 vs
+// 3334 us at 72 x 128 tokens; the barrier across 8 waves costs more than the DMA issue saves.)
 // Register budget (256 at 2 waves per SIMD): O^T of both query blocks is 64 registers, Q 32, the
 // scores of a tile 64.  The 16-register -m_ref and denominator blocks of the kernel above do not fit:
 //   * the reference max is subtracted by a FIFTH k-step instead:  S^T += Kones (keys x 16, column 0
@@ -423,6 +425,16 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const f16* __res
       }
       f16x8 (&pf)[4] = pfb[b];
       float lt;
+      // block 0's P V product goes to the matrix pipe behind block 1's exponentials (its V^T fragments,
+      // requested after softmax 0, have arrived by then); splitting the exponentials around it
+      // measured no better in the full step (17.8 vs 17.7 ms of attention per step)
+      auto pv0 = [&]() {
+#pragma unroll
+        for (int c2 = 0; c2 < 4; ++c2) {
+          o0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[2 * c2], pfb[0][c2], o0[0], 0, 0, 0);
+          o1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[2 * c2 + 1], pfb[0][c2], o1[0], 0, 0, 0);
+        }
+      };
       auto exponentiate = [&]() {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -437,6 +449,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const f16* __res
             lt = __builtin_amdgcn_fdot2(f16x2{pf[c2][2 * jj], pf[c2][2 * jj + 1]}, one2, lt, false);
       };
       exponentiate();
+      if (b == 1) pv0();
       // ---- rare path: move the reference (always on the first tile, which defines it) ----
       if (kt == 0 || __any(!(lt <= 128.f))) {
         float mx = max3_f(s0[0], s1[0], s0[1]);
@@ -478,14 +491,12 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const f16* __res
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- O^T += V^T P^T for both query blocks ----
+    // ---- O^T += V^T P^T, query block 1 ----
 #pragma unroll
-    for (int c2 = 0; c2 < 4; ++c2)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        o0[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[2 * c2], pfb[b][c2], o0[b], 0, 0, 0);
-        o1[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[2 * c2 + 1], pfb[b][c2], o1[b], 0, 0, 0);
-      }
+    for (int c2 = 0; c2 < 4; ++c2) {
+      o0[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[2 * c2], pfb[1][c2], o0[1], 0, 0, 0);
+      o1[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[2 * c2 + 1], pfb[1][c2], o1[1], 0, 0, 0);
+    }
   }
 
   // ---- normalise and store: o{0,1}[r] is O[query l31][d = 32 dt + (r&3) + 8 (r>>2) + 4 half] ----

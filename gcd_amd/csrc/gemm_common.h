@@ -190,14 +190,17 @@ __device__ __forceinline__ void gcd_epilogue_64x160_ln(const GemmK& p, f32x16 (&
 // wave-private LDS tile (`stage`, >= 4608 B): lane -> row 8 qq + (lane >> 3), channels 4 (lane & 7),
 // and the residual vectors are fetched in that layout, D tiles ahead.  sa / sr1 / sr2 are
 // wave-uniform here (the caller checked that one frame_alpha entry serves the whole tile).
-template <bool HAS_R1, bool HAS_R2>
+template <bool HAS_R1, bool HAS_R2, bool OUT16 = false>
 __device__ __forceinline__ void gcd_epi_f32_rows_full(const GemmK& p, f32x16 (&acc)[5][2], int m_base,
                                                      int n_base, int lane, const float* lb, char* stage,
                                                      float sa, float sr1, float sr2) {
   constexpr int D = HAS_R2 ? 1 : 2;
   const int l31 = lane & 31, hh = lane >> 5, rr = lane >> 3, cc = (lane & 7) * 4;
   const int64_t col = n_base + cc;
+  // OUT16: the same pipeline with an fp16 result (the last temporal FF of a transformer, whose blended
+  // output only feeds proj_out): 8 rows x 64 B per store instruction
   float* const op = (float*)p.out + (int64_t)(m_base + rr) * p.ldo + col;
+  f16* const op16 = (f16*)p.out + (int64_t)(m_base + rr) * p.ldo + col;
   const float* const r1p = HAS_R1 ? p.R1 + (int64_t)(m_base + rr) * p.ldr1 + col : nullptr;
   const float* const r2p = HAS_R2 ? p.R2 + (int64_t)(m_base + rr) * p.ldr2 + col : nullptr;
   const int64_t so = 8 * p.ldo, s1 = 8 * p.ldr1, s2 = 8 * p.ldr2;
@@ -233,7 +236,14 @@ __device__ __forceinline__ void gcd_epi_f32_rows_full(const GemmK& p, f32x16 (&a
       v = (v + bv) * sa;
       if (HAS_R1) v += sr1 * q1[b % D][qq];
       if (HAS_R2) v += sr2 * q2[b % D][qq];
-      *(f32x4*)(op + (4 * j + qq) * so + 32 * i) = v;
+      if (OUT16) {
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (f16)v[e];
+        *(f16x4*)(op16 + (4 * j + qq) * so + 32 * i) = o;
+      } else {
+        *(f32x4*)(op + (4 * j + qq) * so + 32 * i) = v;
+      }
     }
     if ((HAS_R1 || HAS_R2) && b + D < 10) fetch(b + D, b % D);
     __builtin_amdgcn_sched_barrier(0);   // keep the pipeline order (and the register budget) as written
@@ -270,6 +280,38 @@ __device__ __forceinline__ void gcd_epi_geglu_rows_full(const GemmK& p, f32x16 (
     const int row = tt / 10, ch = tt - row * 10;
     const f16x8 v = *(const f16x8*)(stage + row * GCD_EPI_ROW_F16 + ch * 16);
     *(f16x8*)(outp + (int64_t)row * p.ldo + ch * 8) = v;
+  }
+}
+
+// fp16 outputs without residuals (the q|k|v projections): each 32-token half of the wave tile is
+// staged as fp16 [32][160] (+16 B row pad) and leaves as 16-byte pieces of 320-byte row segments — 3.2
+// rows per store instruction, against 8 rows x 64 B through the generic fp32-staged path below.
+#define GCD_EPI_ROW_H160 336
+__device__ __forceinline__ void gcd_epi_f16_rows_full(const GemmK& p, f32x16 (&acc)[5][2], int m_base,
+                                                      int n_base, int lane, const float* lb, char* stage) {
+  const int l31 = lane & 31, hh = lane >> 5;
+  const float* lbl = lb + 4 * hh;
+  const float sa = p.s_acc;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 bv = *(const f32x4*)(lbl + 32 * i + 8 * g);
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (f16)((acc[i][j][4 * g + e] + bv[e]) * sa);
+        *(f16x4*)(stage + l31 * GCD_EPI_ROW_H160 + (32 * i + 8 * g + 4 * hh) * 2) = o;
+      }
+    f16* const outp = (f16*)p.out + (int64_t)(m_base + 32 * j) * p.ldo + n_base;
+#pragma unroll
+    for (int it = 0; it < 10; ++it) {
+      const int tt = it * 64 + lane;
+      const int row = tt / 20, ch = tt - row * 20;
+      const f16x8 v = *(const f16x8*)(stage + row * GCD_EPI_ROW_H160 + ch * 16);
+      *(f16x8*)(outp + (int64_t)row * p.ldo + ch * 8) = v;
+    }
   }
 }
 

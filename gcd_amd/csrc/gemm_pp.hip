@@ -374,6 +374,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
     const float* lb = lds_bias + 160 * wn;
     if (EV == 0 && full && p.out_kind == GCD_OUT_GEGLU && (p.ldo & 7) == 0) {
       gcd_epi_geglu_rows_full(p, acc, wm_base, wn_base, elane, lb, smem + wave * GCD_EPI_STAGE_BYTES);
+    } else if (EV == 0 && full && p.out_kind == GCD_OUT_F16 && !p.R1 && !p.R2 && !p.frame_alpha &&
+               (p.ldo & 7) == 0) {
+      gcd_epi_f16_rows_full(p, acc, wm_base, wn_base, elane, lb, smem + wave * GCD_EPI_STAGE_BYTES);
+    } else if (EV == 0 && full && alpha_uni && p.out_kind == GCD_OUT_F16 && p.R1 && p.R2 && (p.ldo & 3) == 0) {
+      float sa = p.s_acc, sr1 = p.s_r1, sr2 = p.s_r2;
+      if (p.frame_alpha) {
+        const float al = p.frame_alpha[m0 / p.rows_per_alpha];
+        sa = 1.0f - al;
+        sr2 = al;
+        if (p.r1_blend) sr1 *= 1.0f - al;
+      }
+      gcd_epi_f32_rows_full<true, true, true>(p, acc, wm_base, wn_base, elane, lb,
+                                              smem + wave * GCD_EPI_STAGE_BYTES, sa, sr1, sr2);
     } else if (EV == 0 && full && alpha_uni && p.out_kind == GCD_OUT_F32) {
       float sa = p.s_acc, sr1 = p.s_r1, sr2 = p.s_r2;
       if (p.frame_alpha) {

@@ -308,6 +308,70 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   }
 }
 
+// Four (two) rows per wavefront, LPR = 16 (32) lanes per row, for C = 320 (640).  The kernel above
+// keeps ONE row per wave in flight behind two 6-step cross-lane reductions and leaves 3/8 of its lanes
+// idle at C = 320 (measured 3.6 TB/s); here a 16-lane group reads 256 contiguous bytes of its row per
+// instruction, the reductions are four DPP adds inside the 16-lane row (no LDS traffic, one extra
+// shuffle for 32 lanes), and the independent rows of a wave overlap each other's latency.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
+template <int NV, int LPR>  // float4 vectors per lane, lanes per row: C = 4 * NV * LPR
+__global__ __launch_bounds__(256) void layernorm16_kernel(
+    const float* __restrict__ x, int64_t ldx, int64_t M, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, const float* __restrict__ addvec, int64_t ld_addvec,
+    int rows_per_vec, float* __restrict__ sum_out, int64_t ld_sum, f16* __restrict__ y,
+    int64_t ldy) {
+  constexpr int C = NV * LPR * 4, RS = LPR * 4;   // RS: floats between a lane's consecutive vectors
+  const int l16 = threadIdx.x & (LPR - 1);
+  const int64_t grp0 = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+  const int64_t ngrp = (int64_t)gridDim.x * (256 / LPR);
+  auto row_sum = [](float v) {
+    v = row16_sum(v);
+    if (LPR == 32) v += __shfl_xor(v, 16);
+    return v;
+  };
+  for (int64_t m = grp0; m < M; m += ngrp) {
+    const float* row = x + m * ldx + l16 * 4;
+    f32x4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = *(const f32x4*)(row + RS * i);
+    if (addvec) {
+      const float* av = addvec + (m / rows_per_vec) * ld_addvec + l16 * 4;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] += *(const f32x4*)(av + RS * i);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = row_sum(s) * (1.0f / (float)C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i][e] - mean;
+        q += d * d;
+      }
+    const float rstd = rsqrtf(row_sum(q) * (1.0f / (float)C) + eps);
+    f16* yr = y + m * ldy + l16 * 4;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const f32x4 g = *(const f32x4*)(gamma + l16 * 4 + RS * i), b = *(const f32x4*)(beta + l16 * 4 + RS * i);
+      f16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (f16)((v[i][e] - mean) * rstd * g[e] + b[e]);
+      *(f16x4*)(yr + RS * i) = o;
+      if (sum_out) *(f32x4*)(sum_out + m * ld_sum + l16 * 4 + RS * i) = v[i];
+    }
+  }
+}
+
 extern "C" int gcd_layernorm_f16(const float* x, int64_t ldx, int64_t M, int C, const float* gamma,
                                  const float* beta, float eps, const float* addvec,
                                  int64_t ld_addvec, int rows_per_vec, float* sum_out,
@@ -319,10 +383,23 @@ extern "C" int gcd_layernorm_f16(const float* x, int64_t ldx, int64_t M, int C, 
   if (addvec)
     GCD_CHECK_ARG(rows_per_vec > 0 && ld_addvec % 4 == 0, "gcd_layernorm_f16: addvec geometry");
   if (sum_out) GCD_CHECK_ARG(ld_sum % 4 == 0, "gcd_layernorm_f16: ld_sum alignment");
+  hipStream_t s = (hipStream_t)stream;
+  if (C == 320 || C == 640) {   // 16 / 32 lanes per row, 5 vectors per lane
+    const int rpb = C == 320 ? 16 : 8;   // rows per 256-thread block
+    int64_t blocks16 = (M + rpb - 1) / rpb;
+    if (blocks16 > 8192) blocks16 = 8192;
+    if (C == 320)
+      hipLaunchKernelGGL((layernorm16_kernel<5, 16>), dim3((unsigned)blocks16), dim3(256), 0, s, x, ldx, M,
+                         gamma, beta, eps, addvec, ld_addvec, rows_per_vec, sum_out, ld_sum, (f16*)y16, ldy);
+    else
+      hipLaunchKernelGGL((layernorm16_kernel<5, 32>), dim3((unsigned)blocks16), dim3(256), 0, s, x, ldx, M,
+                         gamma, beta, eps, addvec, ld_addvec, rows_per_vec, sum_out, ld_sum, (f16*)y16, ldy);
+    GCD_CHECK_LAUNCH();
+    return 0;
+  }
   int64_t blocks = (M + 3) / 4;
   if (blocks > 16384) blocks = 16384;  // grid-stride beyond 8 workgroups per CU
   const int nv = (C / 4 + 63) / 64;
-  hipStream_t s = (hipStream_t)stream;
 #define GCD_LN_LAUNCH(NV)                                                                        \
   hipLaunchKernelGGL(layernorm_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, M, C, \
                      gamma, beta, eps, addvec, ld_addvec, rows_per_vec, sum_out, ld_sum,         \
