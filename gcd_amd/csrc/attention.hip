@@ -208,7 +208,8 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
     }
     // register r of a sub-tile holds key (r&3) + 8*(r>>2) + 4*half
     if ((kt << 6) + 64 > S) {
-      const int kb = (kt << 6) + 4 * half;
+      int kb = (kt << 6) + 4 * half;
+      asm volatile("" : "+v"(kb));   // keeps the key-index adds inside this (last-tile-only) branch
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kb + (r & 3) + 8 * (r >> 2);
@@ -381,8 +382,13 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const f16* __res
     }
     __builtin_amdgcn_s_barrier();
     stage(kt + 2);
-    const char* Ks = smem + (kt % 3) * 16384;
-    const char* Vs = Ks + 8192;
+    // fragment addresses of this stage: four VALU adds, everything else is an immediate ds_read offset
+    // (V^T = +8192, rows 32-63 = +4096); written with a pointer the compiler re-added the stage base to
+    // every one of the 16 reads
+    const int sbase = (kt % 3) * 16384;
+    int fo[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fo[ks] = foff[ks] + sbase;
 
     // ---- S^T - m_ref for both query blocks; K fragments of one 32-key half at a time ----
     f32x16 sc[2][2];   // [query block][key half]
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const f16* __res
     for (int kb = 0; kb < 2; ++kb) {
       f16x8 kf[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const f16x8*)(Ks + foff[ks] + 4096 * kb);
+      for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const f16x8*)(smem + fo[ks] + 4096 * kb);
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         sc[b][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kones, qm[b], zero16, 0, 0, 0);
@@ -415,7 +421,8 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const f16* __res
       }
       // register r of a key half holds key (r&3) + 8*(r>>2) + 4*half
       if ((kt << 6) + 64 > S) {
-        const int kb0 = (kt << 6) + 4 * half;
+        int kb0 = (kt << 6) + 4 * half;
+        asm volatile("" : "+v"(kb0));   // keeps the 32 key-index adds inside this (last-tile-only) branch
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kb0 + (r & 3) + 8 * (r >> 2);
@@ -485,8 +492,8 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const f16* __res
         // V^T fragments: issued between the two softmax passes, their latency hides under the second
 #pragma unroll
         for (int c2 = 0; c2 < 4; ++c2) {
-          vf[2 * c2] = *(const f16x8*)(Vs + foff[c2]);
-          vf[2 * c2 + 1] = *(const f16x8*)(Vs + foff[c2] + 4096);
+          vf[2 * c2] = *(const f16x8*)(smem + fo[c2] + 8192);
+          vf[2 * c2 + 1] = *(const f16x8*)(smem + fo[c2] + 8192 + 4096);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
