@@ -117,6 +117,16 @@ def cpu_baseline(net, T, seed):
                 measured_steps_per_s_at_sample=1.0 / dt)
 
 
+def _pmc_traffic():
+    """HBM-side bytes per GEMM-family launch from the committed PMC passes of this same command
+    (counters cannot be read from inside the process; None if the profile is not shipped)."""
+    f = Path(__file__).resolve().parent / "profiles" / "r01v_hbm_traffic.json"
+    try:
+        return json.loads(f.read_text())["gemm"]["bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -250,12 +260,13 @@ def main():
                        "graph": sampler.use_graph},
             "roofline": {"bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": PEAK_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(gemm_tflops / PEAK_MFMA_TFLOPS, 4),
-                         "traffic": None, "traffic_profile": "profiles/r01k_gemm_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per GEMM shape)",
+                         "traffic": _pmc_traffic(), "traffic_unit": "bytes per launch (fabric-side: HBM + Infinity Cache)",
+                         "traffic_profile": "profiles/r01v_hbm_traffic.{txt,json}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_traffic.py; FETCH x2 per the gfx950 note of MI355X_MICROARCH.md), per shape: profiles/r01k_gemm_hbm_traffic.txt",
                          "kernel": "gemm_pp_kernel + gemm_f16_kernel (MFMA implicit-GEMM family: Linear, Conv2d 3x3/1x1, Conv3d (3,1,1))",
                          "launches_per_step": gk["launches"],
                          "algorithmic_tflop_per_step": round(gk["flops"] / 1e12, 3),
                          "kernel_ms_per_step": round(gk["ms"], 3)},
-            "attention": {"kernel": "attn_spatial_kernel", "achieved": round(
+            "attention": {"kernel": "attn_spatial64_kernel (72x128, 36x64 tokens) + attn_spatial_kernel", "achieved": round(
                 ak["flops"] / (ak["ms"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
                 "algorithmic_tflop_per_step": round(ak["flops"] / 1e12, 3),
                 "kernel_ms_per_step": round(ak["ms"], 3), "launches_per_step": ak["launches"]},
