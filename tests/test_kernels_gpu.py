@@ -186,6 +186,70 @@ def test_gemm_plain_bias_residual(gpu, M, N, K):
     assert e < TOL_F16, f"gemm f16 out M={M} N={N} K={K}: rel-L2 {e:.3e}"
 
 
+@pytest.mark.parametrize("M,N,K", [(768, 320, 64), (1024, 640, 320), (66 * 1024, 320, 96)])
+def test_gemm_full_tile_fast_epilogues(gpu, M, N, K):
+    """Whole 256 x 320 tiles take the row-major pipelined epilogues of the ping-pong kernel
+    (gemm_common.h: gcd_epi_f32_rows_full / gcd_epi_geglu_rows_full / gcd_epi_f16_rows_full); the last
+    shape has more tiles than CUs (persistent walk).  Every combination the UNet uses, with the
+    tile-uniform and the non-uniform (generic fallback) forms of rowvec / frame_alpha."""
+    from gcd_amd import ops, packing
+    ops.tune_set(ops.TUNE_GEMM_IMPL, 2)
+    try:
+        g = _gen(31)
+        a = _h(torch.randn(M, K, generator=g))
+        w = _h(torch.randn(N, K, generator=g) / math.sqrt(K))
+        bias = torch.randn(N, generator=g)
+        r1 = torch.randn(M, N, generator=g)
+        r2 = torch.randn(M, N, generator=g)
+        ag, wg = a.half().to(gpu), w.half().to(gpu)
+        acc = a @ w.t()
+        # residual in place + bias (attention out / FF out / proj_out)
+        x = r1.to(gpu).clone()
+        ops.gemm(ag, wg, x, M=M, bias=bias.to(gpu), r1=x)
+        assert rel_l2(x, acc + bias + r1) < TOL_F32
+        # bias only, scaled
+        out = torch.empty(M, N, device=gpu)
+        ops.gemm(ag, wg, out, M=M, bias=bias.to(gpu), s_acc=0.37)
+        assert rel_l2(out, 0.37 * (acc + bias)) < TOL_F32
+        for rows in (256, 512, 100):      # per-frame vector / alpha: uniform per tile (256, 512) or not (100)
+            rv = torch.randn((M + rows - 1) // rows, N, generator=g)
+            alpha = torch.rand((M + rows - 1) // rows, generator=g)
+            al = alpha.repeat_interleave(rows)[:M, None]
+            rvx = rv.repeat_interleave(rows, 0)[:M]
+            # conv1 / attention-out form: bias + rowvec (+ residual)
+            ops.gemm(ag, wg, out, M=M, bias=bias.to(gpu), rowvec=rv.to(gpu), rows_per_vec=rows, r1=r1.to(gpu))
+            assert rel_l2(out, acc + bias + rvx + r1) < TOL_F32, rows
+            # transformer blend: alpha*x + (1-alpha)*(acc + bias + x_mix), fp32 and fp16 results
+            ref = al * r2 + (1 - al) * (acc + bias + r1)
+            ops.gemm(ag, wg, out, M=M, bias=bias.to(gpu), r1=r1.to(gpu), r2=r2.to(gpu),
+                     frame_alpha=alpha.to(gpu), rows_per_alpha=rows, r1_blend=True)
+            assert rel_l2(out, ref) < TOL_F32, rows
+            out16 = torch.empty(M, N, device=gpu, dtype=torch.float16)
+            ops.gemm(ag, wg, out16, M=M, bias=bias.to(gpu), r1=r1.to(gpu), r2=r2.to(gpu),
+                     frame_alpha=alpha.to(gpu), rows_per_alpha=rows, r1_blend=True, out_kind=ops.OUT_F16)
+            assert rel_l2(out16.float(), ref) < TOL_F16, rows
+            # resblock blend: x_s + (1-alpha)*(acc + bias)
+            ops.gemm(ag, wg, out, M=M, bias=bias.to(gpu), r1=r1.to(gpu), frame_alpha=alpha.to(gpu),
+                     rows_per_alpha=rows, r1_blend=False)
+            assert rel_l2(out, r1 + (1 - al) * (acc + bias)) < TOL_F32, rows
+        # fp16 result without residuals (q|k|v), with and without bias
+        out16 = torch.empty(M, N, device=gpu, dtype=torch.float16)
+        ops.gemm(ag, wg, out16, M=M, out_kind=ops.OUT_F16)
+        assert rel_l2(out16.float(), acc) < TOL_F16
+        ops.gemm(ag, wg, out16, M=M, bias=bias.to(gpu), out_kind=ops.OUT_F16)
+        assert rel_l2(out16.float(), acc + bias) < TOL_F16
+        # GEGLU
+        wp, bp = packing.pack_geglu(w, bias)
+        hid = torch.empty(M, N // 2, device=gpu, dtype=torch.float16)
+        ops.gemm(ag, wp.to(gpu), hid, M=M, bias=bp.to(gpu), out_kind=ops.OUT_GEGLU)
+        lin = acc + bias
+        ref = lin[:, :N // 2] * F.gelu(lin[:, N // 2:])
+        assert rel_l2(hid.float(), ref) < TOL_F16
+        torch.cuda.synchronize()
+    finally:
+        ops.tune_set(ops.TUNE_GEMM_IMPL, 0)
+
+
 def test_gemm_inplace_residual_and_ld(gpu):
     """R1 aliases out (residual stream update in place) and operands are strided views."""
     from gcd_amd import ops
