@@ -175,56 +175,91 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmK p) {
   }
 
   // ---- epilogue: lane holds out[m][nb .. nb+3] for (i = n-tile, j = m-tile) ----
+  // Bias vectors are loaded once, and the residual vectors of m-tile j + 1 are requested before the
+  // stores of m-tile j are issued: the output may alias the residual, so written naively every load
+  // would wait (vmcnt(0)) for the previous store as well (see gemm_common.h).
   const int nq = (lane >> 4) * 4;
+  if (p.out_kind != GCD_OUT_GEGLU) {
+    f32x4 bv[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int n = n0 + wn * WN + i * 16 + nq;
+      bv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (p.bias && n < p.N) bv[i] = *(const f32x4*)(p.bias + n);
+    }
+    f32x4 q1[2][TN], q2[2][TN];
+    auto fetch = [&](int j, int slot) {
+      int m = m0 + wm * WM + j * 16 + (lane & 15);
+      m = m < p.M ? m : p.M - 1;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        int n = n0 + wn * WN + i * 16 + nq;
+        n = n < p.N ? n : p.N - 4;
+        if (p.R1) q1[slot][i] = *(const f32x4*)(p.R1 + (int64_t)m * p.ldr1 + n);
+        if (p.R2) q2[slot][i] = *(const f32x4*)(p.R2 + (int64_t)m * p.ldr2 + n);
+      }
+    };
+    if (p.R1 || p.R2) fetch(0, 0);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m0 + wm * WM + j * 16 + (lane & 15);
+      const int mc = m < p.M ? m : p.M - 1;
+      float sa = p.s_acc, sr1 = p.s_r1, sr2 = p.s_r2;
+      if (p.frame_alpha) {
+        const float al = p.frame_alpha[mc / p.rows_per_alpha];
+        sa = 1.0f - al;
+        sr2 = al;
+        if (p.r1_blend) sr1 *= 1.0f - al;
+      }
+      const float* rv = p.rowvec ? p.rowvec + (int64_t)(mc / p.rows_per_vec) * p.ld_rowvec : nullptr;
+      f32x4 v[TN];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        int n = n0 + wn * WN + i * 16 + nq;
+        n = n < p.N ? n : p.N - 4;
+        v[i] = acc[i][j] + bv[i];
+        if (rv) v[i] += *(const f32x4*)(rv + n);
+        v[i] *= sa;
+        if (p.R1) v[i] += sr1 * q1[j & 1][i];
+        if (p.R2) v[i] += sr2 * q2[j & 1][i];
+      }
+      if ((p.R1 || p.R2) && j + 1 < TM) fetch(j + 1, (j + 1) & 1);
+      if (m < p.M) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int n = n0 + wn * WN + i * 16 + nq;
+          if (n >= p.N) continue;
+          if (p.out_kind == GCD_OUT_F32) {
+            *(f32x4*)((float*)p.out + (int64_t)m * p.ldo + n) = v[i];
+          } else {
+            f16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (f16)v[i][r];
+            *(f16x4*)((f16*)p.out + (int64_t)m * p.ldo + n) = o;
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int m = m0 + wm * WM + j * 16 + (lane & 15);
     if (m >= p.M) continue;
-    float sa = p.s_acc, sr1 = p.s_r1, sr2 = p.s_r2;
-    if (p.frame_alpha) {
-      const float al = p.frame_alpha[m / p.rows_per_alpha];
-      sa = 1.0f - al;
-      sr2 = al;
-      if (p.r1_blend) sr1 *= 1.0f - al;
-    }
-    const float* rv = p.rowvec ? p.rowvec + (int64_t)(m / p.rows_per_vec) * p.ld_rowvec : nullptr;
-    if (p.out_kind == GCD_OUT_GEGLU) {
-      if constexpr ((TN % 2) == 0) {
+    if constexpr ((TN % 2) == 0) {
 #pragma unroll
-        for (int i = 0; i < TN; i += 2) {
-          const int nt = n0 + wn * WN + i * 16;      // value rows nt.., gate rows nt+16..
-          if (nt >= p.N) continue;
-          f32x4 a = acc[i][j], g = acc[i + 1][j];
-          if (p.bias) {
-            a += *(const f32x4*)(p.bias + nt + nq);
-            g += *(const f32x4*)(p.bias + nt + 16 + nq);
-          }
-          f16x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (f16)(a[r] * gelu_fast(g[r]));
-          *(f16x4*)((f16*)p.out + (int64_t)m * p.ldo + (nt >> 1) + nq) = o;
+      for (int i = 0; i < TN; i += 2) {
+        const int nt = n0 + wn * WN + i * 16;      // value rows nt.., gate rows nt+16..
+        if (nt >= p.N) continue;
+        f32x4 a = acc[i][j], g = acc[i + 1][j];
+        if (p.bias) {
+          a += *(const f32x4*)(p.bias + nt + nq);
+          g += *(const f32x4*)(p.bias + nt + 16 + nq);
         }
-      }
-    } else {
+        f16x4 o;
 #pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        const int nb = n0 + wn * WN + i * 16;
-        if (nb >= p.N) continue;
-        const int n = nb + nq;
-        f32x4 v = acc[i][j];
-        if (p.bias) v += *(const f32x4*)(p.bias + n);
-        if (rv) v += *(const f32x4*)(rv + n);
-        v *= sa;
-        if (p.R1) v += sr1 * *(const f32x4*)(p.R1 + (int64_t)m * p.ldr1 + n);
-        if (p.R2) v += sr2 * *(const f32x4*)(p.R2 + (int64_t)m * p.ldr2 + n);
-        if (p.out_kind == GCD_OUT_F32) {
-          *(f32x4*)((float*)p.out + (int64_t)m * p.ldo + n) = v;
-        } else {
-          f16x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (f16)v[r];
-          *(f16x4*)((f16*)p.out + (int64_t)m * p.ldo + n) = o;
-        }
+        for (int r = 0; r < 4; ++r) o[r] = (f16)(a[r] * gelu_fast(g[r]));
+        *(f16x4*)((f16*)p.out + (int64_t)m * p.ldo + (nt >> 1) + nq) = o;
       }
     }
   }
