@@ -11,7 +11,7 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libgcd_amd.so"
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # GEMM modes / output kinds (mirror include/gcd_amd.h)
 GEMM_PLAIN, GEMM_CONV3X3, GEMM_TEMPORAL3 = 0, 1, 2
@@ -40,7 +40,7 @@ class GemmDesc(C.Structure):
         ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("ln_rows_per_vec", C.c_int32),
         ("ln_addvec", C.c_void_p), ("ld_ln_addvec", C.c_int64), ("ln_sum_out", C.c_void_p),
         ("ld_ln_sum", C.c_int64),
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("asym_pad", C.c_int32),
     ]
 
 

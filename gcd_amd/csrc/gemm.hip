@@ -116,8 +116,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmK p) {
           iy = uy >> 1;
           ix = ux >> 1;
         } else {
-          iy = a_y[i] * p.stride + dy;
-          ix = a_x[i] * p.stride + dx;
+          iy = a_y[i] * p.stride + dy + p.asym;
+          ix = a_x[i] * p.stride + dx + p.asym;
           ok = ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
         }
         src = ok ? p.A + (a_off[i] + (int64_t)iy * p.Wi + ix) * p.lda + c0 + cl * 8
@@ -346,6 +346,7 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
   k.Wo = d->Wo;
   k.stride = d->stride;
   k.up = d->upsample;
+  k.asym = d->asym_pad ? 1 : 0;
   k.T = d->T;
   k.HW = d->HW;
   k.bias = d->bias;
@@ -432,6 +433,10 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
       if (d->upsample)
         GCD_CHECK_ARG(d->stride == 1 && d->Ho == 2 * d->Hi && d->Wo == 2 * d->Wi,
                       "gcd_gemm_f16: fused upsample needs Ho=2Hi, Wo=2Wi, stride 1");
+      else if (d->asym_pad)
+        GCD_CHECK_ARG(d->stride == 2 && d->Ho == d->Hi / 2 && d->Wo == d->Wi / 2,
+                      "gcd_gemm_f16: asym_pad needs stride 2 and Ho = Hi/2, Wo = Wi/2 (%dx%d -> %dx%d)",
+                      d->Hi, d->Wi, d->Ho, d->Wo);
       else
         GCD_CHECK_ARG(d->Ho == (d->Hi - 1) / d->stride + 1 && d->Wo == (d->Wi - 1) / d->stride + 1,
                       "gcd_gemm_f16: conv3x3 pad-1 geometry mismatch (%dx%d -> %dx%d, stride %d)",

@@ -10,6 +10,7 @@ struct GemmK {
   int64_t lda, ldo;
   int M, N, K;
   int Cin, Hi, Wi, Ho, Wo, stride, up, T, HW;
+  int asym;   // CONV3X3 stride 2 with (0,1,0,1) padding: taps at 2y + ky, ky = 0..2
   const float* bias;
   const float* rowvec;
   int64_t ld_rowvec;

@@ -104,8 +104,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
           iy = uy >> 1;
           ix = ux >> 1;
         } else {
-          iy = a_y[i] * p.stride + dy;
-          ix = a_x[i] * p.stride + dx;
+          iy = a_y[i] * p.stride + dy + p.asym;
+          ix = a_x[i] * p.stride + dx + p.asym;
           ok = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
         }
         a_base[i] = ok ? (const char*)p.A + (a_fb[i] + (int64_t)iy * p.Wi + ix) * p.lda * 2 + lc16

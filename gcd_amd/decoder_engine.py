@@ -42,6 +42,33 @@ class DecoderEngine:
         self.packed = None
 
     # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _pack_resnet2d(rb) -> dict:
+        """fp16 GEMM operands of a ResnetBlock (norm1, conv1, norm2, conv2, nin_shortcut)."""
+        L = dict(cin=rb.in_channels, cout=rb.out_channels)
+        for c in (L["cin"], L["cout"]):
+            if c % 32:
+                raise NotImplementedError(f"autoencoder channel count {c} is not a multiple of 32")
+        L["gn1"] = (_f32(rb.norm1.weight), _f32(rb.norm1.bias))
+        L["gn2"] = (_f32(rb.norm2.weight), _f32(rb.norm2.bias))
+        L["w1"], L["b1"] = packing.pack_conv3x3(rb.conv1.weight), _f32(rb.conv1.bias)
+        L["w2"], L["b2"] = packing.pack_conv3x3(rb.conv2.weight), _f32(rb.conv2.bias)
+        if rb.in_channels != rb.out_channels:
+            L["wskip"] = packing.pack_conv1x1(rb.nin_shortcut.weight)
+            L["bskip"] = _f32(rb.nin_shortcut.bias)
+        else:
+            L["wskip"] = None
+        return L
+
+    @staticmethod
+    def _pack_attn(a) -> dict:
+        return dict(
+            C=a.in_channels, gn=(_f32(a.norm.weight), _f32(a.norm.bias)),
+            wqv=torch.cat([packing.pack_conv1x1(a.q.weight), packing.pack_conv1x1(a.v.weight)], 0).contiguous(),
+            bqv=torch.cat([_f32(a.q.bias), _f32(a.v.bias)]).contiguous(),
+            wk=packing.pack_conv1x1(a.k.weight), bk=_f32(a.k.bias),
+            wo=packing.pack_conv1x1(a.proj_out.weight), bo=_f32(a.proj_out.bias))
+
     def pack(self) -> None:
         d = self.dec
         dev = d.conv_in.weight.device
@@ -54,18 +81,8 @@ class DecoderEngine:
             return (_f32(m.weight), _f32(m.bias))
 
         def res(rb):
-            L = dict(cin=rb.in_channels, cout=rb.out_channels, alpha=rb.alpha())
-            for c in (L["cin"], L["cout"]):
-                if c % 32:
-                    raise NotImplementedError(f"VideoDecoder channel count {c} is not a multiple of 32")
-            L["gn1"], L["gn2"] = gn(rb.norm1), gn(rb.norm2)
-            L["w1"], L["b1"] = packing.pack_conv3x3(rb.conv1.weight), _f32(rb.conv1.bias)
-            L["w2"], L["b2"] = packing.pack_conv3x3(rb.conv2.weight), _f32(rb.conv2.bias)
-            if rb.in_channels != rb.out_channels:
-                L["wskip"] = packing.pack_conv1x1(rb.nin_shortcut.weight)
-                L["bskip"] = _f32(rb.nin_shortcut.bias)
-            else:
-                L["wskip"] = None
+            L = self._pack_resnet2d(rb)
+            L["alpha"] = rb.alpha()
             ts = rb.time_stack
             L["tgn1"], L["tgn2"] = gn(ts.in_layers[0]), gn(ts.out_layers[0])
             L["tw1"], L["tb1"] = packing.pack_conv_t3(ts.in_layers[2].weight), _f32(ts.in_layers[2].bias)
@@ -76,14 +93,7 @@ class DecoderEngine:
         P["conv_in_w"] = packing.pack_conv3x3(d.conv_in.weight, cin_pad=CIN_PAD)
         P["conv_in_b"] = _f32(d.conv_in.bias)
         P["mid1"], P["mid2"] = res(d.mid.block_1), res(d.mid.block_2)
-        a = d.mid.attn_1
-        Ca = a.in_channels
-        P["attn"] = dict(
-            C=Ca, gn=gn(a.norm),
-            wqv=torch.cat([packing.pack_conv1x1(a.q.weight), packing.pack_conv1x1(a.v.weight)], 0).contiguous(),
-            bqv=torch.cat([_f32(a.q.bias), _f32(a.v.bias)]).contiguous(),
-            wk=packing.pack_conv1x1(a.k.weight), bk=_f32(a.k.bias),
-            wo=packing.pack_conv1x1(a.proj_out.weight), bo=_f32(a.proj_out.bias))
+        P["attn"] = self._pack_attn(d.mid.attn_1)
         P["up"] = []
         for i_level in range(d.num_resolutions):
             up = d.up[i_level]
@@ -122,10 +132,9 @@ class DecoderEngine:
         ws.release(partial, stats)
         return y, raw
 
-    def _resblock(self, L, x, st):
-        """VideoResBlock.forward (temporal_ae.py:56-81): ResnetBlock (model.py:125-153, temb None)
-        -> time_stack (openaimodel.py:331-357 with skip_t_emb) -> alpha merge.  Consumes x."""
-        ws, N, T = self.ws, st["N"], st["T"]
+    def _resnet2d(self, L, x, st):
+        """ResnetBlock.forward with temb None (model.py:129-153).  Consumes x."""
+        ws, N = self.ws, st["N"]
         H, W = st["H"], st["W"]
         HW = H * W
         M = N * HW
@@ -146,6 +155,16 @@ class DecoderEngine:
             xs = x
             ops.gemm(a16, L["w2"], xs, M=M, mode=GEMM_CONV3X3, bias=L["b2"], r1=x, conv=conv2)
         ws.release(a16)
+        return xs, h1
+
+    def _resblock(self, L, x, st):
+        """VideoResBlock.forward (temporal_ae.py:56-81): ResnetBlock (model.py:125-153, temb None)
+        -> time_stack (openaimodel.py:331-357 with skip_t_emb) -> alpha merge.  Consumes x."""
+        ws, N, T = self.ws, st["N"], st["T"]
+        HW = st["H"] * st["W"]
+        M = N * HW
+        cout = L["cout"]
+        xs, h1 = self._resnet2d(L, x, st)
         tconv = dict(Cin=cout, T=T, HW=HW)
         a16, _ = self._gn(xs, T * HW, 1e-5, L["tgn1"], True)
         ops.gemm(a16, L["tw1"], h1, M=M, mode=GEMM_TEMPORAL3, bias=L["tb1"], conv=tconv)

@@ -134,6 +134,7 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mod
         d.Hi, d.Wi = conv.get("Hi", 0), conv.get("Wi", 0)
         d.Ho, d.Wo = conv.get("Ho", 0), conv.get("Wo", 0)
         d.stride, d.upsample = conv.get("stride", 1), int(conv.get("upsample", 0))
+        d.asym_pad = int(conv.get("asym_pad", 0))
         d.T, d.HW = conv.get("T", 0), conv.get("HW", 0)
         d.zero_page = zero_page(a16.device).data_ptr()
     d.bias = _p(bias)

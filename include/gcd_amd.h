@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GCD_AMD_ABI_VERSION 2
+#define GCD_AMD_ABI_VERSION 3
 
 /* ---- library ------------------------------------------------------------------------------ */
 int gcd_abi_version(void);
@@ -117,6 +117,10 @@ typedef struct gcd_gemm_desc {
      4 * M * N * 4 bytes to be used; NULL or too small = never split.                               */
   void* workspace;
   int64_t workspace_bytes;
+  /* CONV3X3, stride 2 only: 1 = the asymmetric (0,1,0,1) zero padding of the autoencoder's Downsample
+     (F.pad + Conv2d(stride 2, padding 0), diffusionmodules/model.py:76-91): input pixel
+     (2y + ky, 2x + kx), ky, kx in 0..2, Ho = Hi / 2; 0 = the symmetric padding 1 of every other conv. */
+  int32_t asym_pad;
 } gcd_gemm_desc;
 
 /* Replaces torch.nn.Linear / Conv2d / Conv3d forward on the hot path:
