@@ -45,19 +45,21 @@ __global__ __launch_bounds__(512) void gn_stats_partial_kernel(
       ld = ld2;
     }
     double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
-    // two rows in flight per thread
+    // four rows in flight per thread
     int64_t r = r0 + ty;
-    for (; r + rpp < r1; r += 2 * rpp) {
+    for (; r + 3 * rpp < r1; r += 4 * rpp) {
       const f32x4 v = *(const f32x4*)(src + (base + r) * ld);
       const f32x4 w = *(const f32x4*)(src + (base + r + rpp) * ld);
+      const f32x4 y = *(const f32x4*)(src + (base + r + 2 * rpp) * ld);
+      const f32x4 z = *(const f32x4*)(src + (base + r + 3 * rpp) * ld);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const double d = (double)v[e], f = (double)w[e];
-        s[e] += d + f;
-        ss[e] += d * d + f * f;
+        const double d = (double)v[e], f = (double)w[e], g = (double)y[e], h = (double)z[e];
+        s[e] += (d + f) + (g + h);
+        ss[e] += (d * d + f * f) + (g * g + h * h);
       }
     }
-    if (r < r1) {
+    for (; r < r1; r += rpp) {
       const f32x4 v = *(const f32x4*)(src + (base + r) * ld);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
