@@ -222,3 +222,23 @@ def test_unet_full_width_kubric_and_pardom(gpu):
         assert e < TOL_FWD, f"full-width UNet (aux={cfg.aux_emb_dim}): rel-L2 {e:.3e}"
         del net, sd
         torch.cuda.empty_cache()
+
+
+def test_sampler_25_steps_full_width_vs_oracle(gpu):
+    """The contract at the real width: the 1.5 B-parameter Kubric VideoUNet, 25 EulerEDM steps with
+    CFG on a 14-frame clip (16x16 latents so that the fp32 CPU oracle finishes in ~2 minutes),
+    final latents within 1e-3 rel-L2 of the oracle."""
+    net, sd = _build(O.KUBRIC, gpu, salt=2)
+    T, steps, h, w = 14, 25, 16, 16
+    noise, c, uc = weights.synth_inputs(1, T, h, w, O.KUBRIC.context_dim,
+                                        O.KUBRIC.adm_in_channels + O.KUBRIC.aux_emb_dim, 91)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = O.sample_loop(sd, O.KUBRIC, noise, c, uc, T, steps)
+    den, model, extra, fused = _stack(net, T, gpu)
+    sampler = _sampler(T, steps, "cuda")
+    out = sampler(fused, noise.clone().to(gpu), cond={k: v.to(gpu) for k, v in c.items()},
+                  uc={k: v.to(gpu) for k, v in uc.items()})
+    e = rel_l2(out, ref)
+    print(f"full-width 25-step loop rel-L2 {e:.3e}")
+    assert sampler.last_path == "fused" and e < TOL_LOOP, f"full-width 25-step loop: rel-L2 {e:.3e}"
