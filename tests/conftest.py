@@ -13,6 +13,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The C-ABI library is a build product (git-ignored): on a fresh checkout compile it before the
+    first test needs it (hipcc cross-compiles gfx950 without a GPU; a few minutes, once)."""
+    lib = ROOT / "gcd_amd" / "libgcd_amd.so"
+    if not lib.exists():
+        from gcd_amd.csrc import build as _b
+        _b.build(verbose=False)
+
+
 def rel_l2(a, b):
     """||a - b||_2 / ||b||_2 in fp64 (b is the reference)."""
     import torch
