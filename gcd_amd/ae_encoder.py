@@ -113,6 +113,30 @@ class Encoder(nn.Module):
         return self.engine.forward(x)
 
 
+class AutoencoderKLModeOnly(nn.Module):
+    """Encode side of `sgm.models.autoencoder.AutoencoderKLModeOnly` (autoencoder.py:458-500,627-640) as
+    the conditioner uses it (`VideoPredictionEmbedderWithEncoder`, is_ae=True): HIP `Encoder` ->
+    1x1 `quant_conv` -> mode of the diagonal Gaussian.  Parameter names `encoder.*`, `quant_conv.*`,
+    `post_quant_conv.*` as in the checkpoints; the image `decoder.*` tensors of that class are not
+    needed for conditioning and are not instantiated (load with strict=False, as
+    DiffusionEngine.init_from_ckpt does)."""
+
+    def __init__(self, embed_dim: int, ddconfig: dict, **ignored):
+        super().__init__()
+        self.encoder = Encoder(**ddconfig)
+        mult = 2 if ddconfig.get("double_z", True) else 1
+        self.quant_conv = nn.Conv2d(mult * ddconfig["z_channels"], mult * embed_dim, 1)
+        self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
+        self.embed_dim = embed_dim
+
+    def encode(self, x: torch.Tensor, return_reg_log: bool = False):
+        z = encode_mode(self.encoder, x, self.quant_conv)
+        return (z, dict()) if return_reg_log else z
+
+    def forward(self, x: torch.Tensor):
+        return self.encode(x)
+
+
 def encode_mode(encoder: Encoder, x: torch.Tensor, quant_conv: Optional[nn.Conv2d] = None) -> torch.Tensor:
     """`AutoencoderKLModeOnly.encode` (autoencoder.py:480-500 with the `sample: False` regularizer,
     regularizers/__init__.py:13-31): moments -> optional 1x1 quant_conv -> the Gaussian's mode = the

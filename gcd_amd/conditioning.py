@@ -99,3 +99,56 @@ class ConcatTimestepEmbedderND(AbstractEmbModel):
         emb = torch.empty(b * dims, self.outdim, device=x.device, dtype=torch.float32)
         ops.timestep_embedding(flat, emb, 10000.0)
         return emb.reshape(b, dims * self.outdim)
+
+
+class VideoPredictionEmbedderWithEncoder(AbstractEmbModel):
+    """Drop-in for `sgm.modules.encoders.modules.VideoPredictionEmbedderWithEncoder`
+    (encoders/modules.py:1037-1114): the conditioning frames -> first-stage latents that become
+    `cond['concat']`.  Same constructor keywords and forward; the encoder named by
+    `encoder_config` is typically `gcd_amd.ae_encoder.AutoencoderKLModeOnly` (is_ae=True).  The
+    optional noise augmentation (`sigma_sampler_config`, training only) is plain torch, as in the
+    reference."""
+
+    def __init__(self, n_cond_frames: int, n_copies: int, encoder_config: dict,
+                 sigma_sampler_config=None, sigma_cond_config=None, is_ae: bool = False,
+                 scale_factor: float = 1.0, disable_encoder_autocast: bool = False,
+                 en_and_decode_n_samples_a_time=None):
+        super().__init__()
+        from .util import instantiate_from_config
+        self.n_cond_frames = n_cond_frames
+        self.n_copies = n_copies
+        self.encoder = instantiate_from_config(encoder_config)
+        self.sigma_sampler = instantiate_from_config(sigma_sampler_config) \
+            if sigma_sampler_config is not None else None
+        self.sigma_cond = instantiate_from_config(sigma_cond_config) \
+            if sigma_cond_config is not None else None
+        self.is_ae = is_ae
+        self.scale_factor = scale_factor
+        self.disable_encoder_autocast = disable_encoder_autocast
+        self.en_and_decode_n_samples_a_time = en_and_decode_n_samples_a_time
+
+    def forward(self, vid: torch.Tensor):
+        import math
+        from .util import append_dims
+        sigma_cond = None
+        if self.sigma_sampler is not None:
+            b = vid.shape[0] // self.n_cond_frames
+            sigmas = self.sigma_sampler(b).to(vid.device)
+            if self.sigma_cond is not None:
+                sigma_cond = self.sigma_cond(sigmas)
+                sigma_cond = sigma_cond.repeat_interleave(self.n_copies, dim=0)     # b d -> (b t) d
+            sigmas = sigmas.repeat_interleave(self.n_cond_frames)                   # b -> (b t)
+            vid = vid + torch.randn_like(vid) * append_dims(sigmas, vid.ndim)
+        n_samples = self.en_and_decode_n_samples_a_time \
+            if self.en_and_decode_n_samples_a_time is not None else vid.shape[0]
+        n_rounds = math.ceil(vid.shape[0] / n_samples)
+        all_out = []
+        for n in range(n_rounds):
+            chunk = vid[n * n_samples:(n + 1) * n_samples]
+            all_out.append(self.encoder.encode(chunk) if self.is_ae else self.encoder(chunk))
+        z = torch.cat(all_out, dim=0) * self.scale_factor
+        bt, c, h, w = z.shape
+        t = self.n_cond_frames
+        z = z.reshape(bt // t, 1, t * c, h, w)                                       # (b t) c h w -> b () (t c) h w
+        z = z.expand(-1, self.n_copies, -1, -1, -1).reshape(-1, t * c, h, w)         # b 1 c h w -> (b t) c h w
+        return (z, sigma_cond) if sigma_cond is not None else z

@@ -115,3 +115,30 @@ def test_full_width_encoder_and_mode(gpu):
     assert enc(x.half().to(gpu)).dtype == torch.float16
     with pytest.raises(ValueError):
         enc(x[..., :100].to(gpu))
+
+
+def test_video_prediction_embedder_with_hip_encoder(gpu):
+    """The conditioner socket that produces cond['concat']: VideoPredictionEmbedderWithEncoder over the
+    HIP AutoencoderKLModeOnly (config of infer_kubric.yaml:69-101 at tiny width) vs the oracle."""
+    from gcd_amd.conditioning import VideoPredictionEmbedderWithEncoder
+    dd = dict(E.TINY.as_reference_kwargs(), attn_type="vanilla-xformers")
+    emb = VideoPredictionEmbedderWithEncoder(
+        n_cond_frames=1, n_copies=1, is_ae=True, disable_encoder_autocast=True,
+        en_and_decode_n_samples_a_time=2, scale_factor=0.18215,
+        encoder_config={"target": "gcd_amd.ae_encoder.AutoencoderKLModeOnly",
+                        "params": {"embed_dim": 4, "monitor": "val/rec_loss", "ddconfig": dd,
+                                   "lossconfig": {"target": "torch.nn.Identity"}}})
+    shapes = {k: tuple(v.shape) for k, v in emb.state_dict().items()}
+    assert len(shapes) == 106 + 4 and "encoder.quant_conv.weight" in shapes
+    sd = weights.synth_state_dict(shapes, salt=6)
+    emb.load_state_dict(sd)
+    emb = emb.to(gpu).eval()
+    vid = images(5, 64, 96, seed=33)                    # 5 frames, chunks of 2 + 2 + 1
+    enc_sd = {k[len("encoder.encoder."):]: v for k, v in sd.items() if k.startswith("encoder.encoder.")}
+    with torch.no_grad():
+        ref = E.encode_mode(enc_sd, E.TINY, vid, sd["encoder.quant_conv.weight"],
+                            sd["encoder.quant_conv.bias"]) * 0.18215
+    out = emb(vid.to(gpu))
+    e = rel_l2(out, ref)
+    print(f"VideoPredictionEmbedderWithEncoder: rel-L2 {e:.3e}")
+    assert out.shape == (5, 4, 8, 12) and e < TOL

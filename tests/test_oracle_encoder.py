@@ -89,3 +89,36 @@ def test_golden_is_reproducible_from_the_reference(gold):
     with torch.no_grad():
         out = enc(images(gold["n"], gold["h"], gold["w"], gold["input_seed"]))
     assert rel_l2(out, gold["out"]) < 1e-6
+
+
+def test_video_prediction_embedder_host_logic_matches_the_reference_rearranges():
+    """VideoPredictionEmbedderWithEncoder.forward (encoders/modules.py:1071-1114) with a stub encoder:
+    chunking by en_and_decode_n_samples_a_time, scale_factor, and the two einops patterns
+    "(b t) c h w -> b () (t c) h w" / "b 1 c h w -> (b t) c h w" restated with reshape / expand."""
+    from einops import rearrange, repeat
+    from gcd_amd.conditioning import VideoPredictionEmbedderWithEncoder
+
+    class Stub(torch.nn.Module):
+        calls = []
+
+        def encode(self, x):
+            Stub.calls.append(x.shape[0])
+            return x[:, :2, ::2, ::2] * 3.0 + 1.0
+
+    g = torch.Generator().manual_seed(4)
+    for n_cond, n_copies, bsz, chunk in [(1, 1, 4, 2), (2, 3, 3, 4), (1, 5, 2, None)]:
+        Stub.calls = []
+        emb = VideoPredictionEmbedderWithEncoder(
+            n_cond_frames=n_cond, n_copies=n_copies, is_ae=True, scale_factor=0.18215,
+            en_and_decode_n_samples_a_time=chunk,
+            encoder_config={"target": "torch.nn.Identity"})
+        emb.encoder = Stub()
+        vid = torch.randn(bsz * n_cond, 3, 8, 12, generator=g)
+        out = emb(vid)
+        ref = Stub().encode(vid) * 0.18215
+        ref = rearrange(ref, "(b t) c h w -> b () (t c) h w", t=n_cond)
+        ref = repeat(ref, "b 1 c h w -> (b t) c h w", t=n_copies)
+        assert out.shape == ref.shape == (bsz * n_copies, 2 * n_cond, 4, 6)
+        assert torch.allclose(out, ref, atol=1e-6)
+        want = [vid.shape[0]] if chunk is None else [min(chunk, vid.shape[0] - i) for i in range(0, vid.shape[0], chunk)]
+        assert Stub.calls[:len(want)] == want
