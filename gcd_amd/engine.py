@@ -489,16 +489,18 @@ class UNetEngine:
         or per clip from the first frame's context (temporal, video_attention.py:244-253).
 
         The vectors depend on the context and the weights only, not on the noise level, so they are
-        kept across calls for as long as the caller passes the same (unmodified) context tensor —
-        every step of a sampling loop after the first (keyed on storage address + torch's in-place
-        version counter; `pack()` clears the cache when the weights change)."""
+        kept across calls for as long as the caller passes the SAME tensor object, unmodified — every
+        step of the fused sampling loop after the first (`pack()` clears the cache when the weights
+        change).  Identity, not address: the cache holds a reference to the tensor, so its storage
+        cannot be freed and handed to a different context at the same address while the entry lives
+        (a (data_ptr, _version) key would silently reuse the vectors of the previous clip there);
+        in-place edits bump torch's version counter and miss."""
         P = self.packed
         N, T = st["N"], st["T"]
-        key = (context_src.data_ptr(), context_src._version, tuple(context_src.shape),
-               context_src.dtype, N, T)
+        key = (context_src._version, tuple(context_src.shape), context_src.dtype, N, T)
         hit = P.get("ca_cache")
-        if hit is not None and hit[0] == key:
-            return hit[1]
+        if hit is not None and hit[0] is context_src and hit[1] == key:
+            return hit[2]
         dev = context.device
         v_all = torch.empty((N, P["ca_total"]), dtype=torch.float32, device=dev)
         ops.linear_smallm(context, P["ca_wv"], None, v_all)
@@ -510,7 +512,7 @@ class UNetEngine:
             o = torch.empty((src.shape[0], m["C"]), dtype=torch.float32, device=dev)
             ops.linear_smallm(src, m["wo"], m["bo"], o)
             outs.append(o)
-        P["ca_cache"] = (key, outs, v_all)
+        P["ca_cache"] = (context_src, key, outs, v_all)
         return outs
 
     # ------------------------------------------------------------------------------------------

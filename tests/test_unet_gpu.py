@@ -99,6 +99,36 @@ def test_unet_image_only_indicator_and_repeatability(gpu, tiny):
     assert torch.equal(out1, out2), "forward is not bit-reproducible run to run"
 
 
+def test_cross_attention_cache_survives_address_reuse(gpu, tiny):
+    """The collapsed cross-attention vectors are cached per context TENSOR OBJECT.  A new clip's
+    context that the allocator places at the freed address of the previous one (same shape, same
+    version counter) must not be served the previous clip's vectors."""
+    net, sd = tiny
+    T, h, w = 4, 8, 8
+    x, ts, ctx_a, y, ioi = _unet_inputs(O.TINY, T, h, w, 33)
+    ctx_b = torch.randn(ctx_a.shape, generator=torch.Generator().manual_seed(34)) * 2.0
+    kw = dict(y=y.to(gpu), num_video_frames=T, image_only_indicator=ioi.to(gpu))
+    xg, tg = x.to(gpu), ts.to(gpu)
+    ca = ctx_a.to(gpu)
+    ptr = ca.data_ptr()
+    out_a = net(xg, tg, context=ca, **kw)
+    out_a2 = net(xg, tg, context=ca, **kw)                 # same object: cache hit, same result
+    assert torch.equal(out_a, out_a2)
+    del ca
+    cb = ctx_b.to(gpu)                                      # usually lands on the freed block
+    reused = cb.data_ptr() == ptr
+    out_b = net(xg, tg, context=cb, **kw)
+    with torch.no_grad():
+        ref_b = O.unet_forward(sd, O.TINY, x, ts, ctx_b, y, T, ioi)
+    print(f"address reused: {reused}; rel-L2 vs oracle {rel_l2(out_b, ref_b):.3e}")
+    assert rel_l2(out_b, ref_b) < TOL_FWD and rel_l2(out_b, out_a) > 1e-2
+    cb.mul_(0.5)                                            # in-place edit: version bump -> miss
+    out_c = net(xg, tg, context=cb, **kw)
+    with torch.no_grad():
+        ref_c = O.unet_forward(sd, O.TINY, x, ts, ctx_b * 0.5, y, T, ioi)
+    assert rel_l2(out_c, ref_c) < TOL_FWD
+
+
 def test_unet_rejects_bad_inputs(gpu, tiny):
     net, _ = tiny
     x, ts, ctx, y, ioi = _unet_inputs(O.TINY, 2, 8, 8, 41)
