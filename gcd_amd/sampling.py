@@ -185,6 +185,7 @@ class FusedEulerLoop:
         self.side = torch.cuda.Stream(device=dev)
         self._ctx = None
         self._eager_done = 0
+        self._keepalive = None
 
     # the side stream is current inside `with loop:` so that every launch lands on it
     def __enter__(self):
@@ -220,6 +221,9 @@ class FusedEulerLoop:
             finally:
                 _lib.check(self.lib.gcd_graph_end_capture(self.side.cuda_stream, C.byref(self.graph)),
                            "graph instantiate")
+            # the captured launches read the engine's cached cross-attention vectors: keep them alive
+            # for the graph's lifetime even if another call replaces the engine's cache entry
+            self._keepalive = self.eng.packed.get("ca_cache")
             _lib.check(self.lib.gcd_graph_launch(self.graph, self.side.cuda_stream), "graph launch")
         else:
             _lib.check(self.lib.gcd_graph_launch(self.graph, self.side.cuda_stream), "graph launch")
