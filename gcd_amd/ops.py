@@ -97,9 +97,12 @@ _SPLITK_ON = os.environ.get("GCD_SPLITK", "1") != "0"   # A/B switch
 
 
 def _splitk_ws(device) -> torch.Tensor:
-    """Persistent split-K scratch per device (gcd_gemm_desc.workspace): 4 partial outputs of the
-    largest few-tile problem of the SVD UNet, 4032 tokens x 1280 channels fp32 = 83 MB."""
-    key = torch.device(device).index or 0
+    """Persistent split-K scratch (gcd_gemm_desc.workspace): 4 partial outputs of the largest few-tile
+    problem of the SVD UNet, 4032 tokens x 1280 channels fp32 = 83 MB.  One per (device, stream): the
+    partial sums of a launch live there until its reduce kernel has run, so two streams must not
+    share it.  Entries are never dropped (captured hipGraphs hold the pointer); torch hands out stream
+    handles from a fixed pool, which bounds their number."""
+    key = (torch.device(device).index or 0, _stream())
     w = _splitk.get(key)
     if w is None:
         w = torch.empty(4 * 4096 * 1280, dtype=torch.float32, device=device)
