@@ -20,7 +20,14 @@ Prints ONE JSON line on rank 0 (see the driver contract), including
                 region (the timed region itself replays a hipGraph, which has no per-kernel hooks);
   cpu_baseline  the CPU oracle (oracle/svd_unet_ref.py, a port of the reference's PyTorch path)
                 timed on this box's host cores on a bounded sample (one step at 14 x 32 x 32
-                latents), scaled to the metric's unit by the algorithmic FLOP ratio.
+                latents = BASELINE.json cfg0), scaled to the metric's unit by the algorithmic FLOP
+                ratio; next to it the reference itself measured at the metric's shape (BASELINE.md §2);
+  parity        the SAME cfg0 step (same weights, same inputs) run through the HIP path and compared
+                with the oracle result of the cpu_baseline leg: rel-L2 of x_next; the bench exits
+                non-zero if it exceeds 2e-3.
+
+`python bench.py --gpus N` with N > 1 and no torchrun environment re-launches itself under
+`torch.distributed.run` (one rank per GPU, RCCL); under the driver's own torchrun it just runs.
 """
 from __future__ import annotations
 
@@ -67,64 +74,131 @@ def build_model(dev, seed=0):
     return net.eval()
 
 
-def synth_inputs(dev, T, h, w, seed):
+def pose_conditioner(dev, seed=7):
+    """The `vector` half of GCD's conditioner (configs/infer_kubric.yaml:52-109): 3 x sinusoid(256)
+    of fps_id / motion_bucket_id / cond_aug + SphericalEmbedder(13 -> 128) with seeded weights."""
+    from gcd_amd.conditioning import GeneralConditioner
+    P = "gcd_amd.conditioning."
+    torch.manual_seed(seed)
+    return GeneralConditioner([
+        dict(input_key="fps_id", target=P + "ConcatTimestepEmbedderND", params=dict(outdim=256)),
+        dict(input_key="motion_bucket_id", is_trainable=True, target=P + "ConcatTimestepEmbedderND",
+             params=dict(outdim=256)),
+        dict(input_key="cond_aug", target=P + "ConcatTimestepEmbedderND", params=dict(outdim=256)),
+        dict(input_key="scaled_relative_angles", is_trainable=True, target=P + "SphericalEmbedder",
+             params=dict(embed_dim=128, zero_init=False))]).to(dev)
+
+
+def synth_inputs(dev, T, h, w, seed, cond=None):
+    """What DiffusionEngine.sample_video hands the sampler (diffusion.py:522-543):
+    noise, c, uc.  crossattn / concat are N(0,1)-shaped stand-ins for the CLIP token and the VAE
+    latents of the conditioning frames; `vector` is the real thing: the conditioner's embedding of
+    fps_id 12, motion_bucket_id 127, cond_aug 0.02 and the gradual camera trajectory
+    0 -> (30 deg, 15 deg, 1 m) over 13 of the 14 frames (eval_utils.py:235-245, common.py:450-479)."""
+    from gcd_amd.camera import scaled_relative_angles
     g = torch.Generator(device=dev).manual_seed(seed)
     n = T
     noise = torch.randn(n, 4, h, w, generator=g, device=dev)
+    cond = cond if cond is not None else pose_conditioner(dev)
+    batch = {"fps_id": torch.full((n,), 12.0, device=dev),
+             "motion_bucket_id": torch.full((n,), 127.0, device=dev),
+             "cond_aug": torch.full((n,), 0.02, device=dev),
+             "scaled_relative_angles": scaled_relative_angles(30.0, 15.0, 1.0, num_frames=T, device=dev)}
     c = {"crossattn": torch.randn(n, 1, 1024, generator=g, device=dev),
          "concat": torch.randn(n, 4, h, w, generator=g, device=dev) * 0.8,
-         "vector": torch.randn(n, 896, generator=g, device=dev).clamp(-1, 1)}
+         "vector": cond(batch)["vector"].detach()}
+    assert c["vector"].shape == (n, 896)
     uc = {"crossattn": torch.zeros_like(c["crossattn"]), "concat": torch.zeros_like(c["concat"]),
           "vector": c["vector"].clone()}
     return noise, c, uc
 
 
-def cpu_baseline(net, T, seed):
-    """Oracle (port of the reference's CPU path) on the host cores.  Bounded sample: one sampler
-    step at 14x16x16 latents first; if that took < 6 s, one more at 14x32x32 (the reported one).
-    Threads are capped at 32: on a 256-core host torch's intra-op pool gets *slower* beyond that on
-    these conv / GEMM sizes (measured 0.02 TFLOP/s with 256 threads vs 0.6 with 8)."""
+PARITY_TOL = 2e-3
+PARITY_SIGMAS = (3.0, 2.0)     # a mid-schedule step: x and the denoised prediction weigh alike in x_next
+# BASELINE.md §2: the unmodified reference modules, fp32, 8 threads, ONE step at the metric's shape
+REFERENCE_AT_SHAPE = dict(value=0.0054, unit="steps/s", cores=8, seconds_per_step=185.1,
+                          provenance="BASELINE.md §2 / SURVEY.md §6: reference VideoUNet + EulerEDM "
+                                     "step via oracle/ref_shim.py at 14x72x128 latents on the build "
+                                     "container's 8 cores (the reference tree does not exist on the GPU "
+                                     "box); re-measured while generating tests/golden/"
+                                     "unet_kubric_72x128.pt (forward only)")
+
+
+def cpu_baseline_and_parity(net, sampler, fd, T, dev, seed, cond):
+    """cfg0 of BASELINE.json, twice on the same weights and inputs:
+      * the oracle (port of the reference's CPU path) on the host cores, timed -> cpu_baseline.
+        Bounded sample: one sampler step at 14x16x16 latents first; if that took < 6 s, one more at
+        14x32x32 (the reported one).  Threads are capped at 32: on a 256-core host torch's intra-op
+        pool gets *slower* beyond that on these conv / GEMM sizes;
+      * the HIP path (one fused step) -> parity = rel-L2 of x_next against the oracle's."""
+    from gcd_amd.sampling import FusedEulerLoop
     from oracle import svd_unet_ref as O
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
     scale = O.guider_scale(T)
     ioi2 = torch.zeros(2, T)
+    sig, nxt = PARITY_SIGMAS
 
     def one(hw):
-        g = torch.Generator().manual_seed(seed)
-        x = torch.randn(T, 4, hw, hw, generator=g) * 700.0
-        c = {"crossattn": torch.randn(T, 1, 1024, generator=g),
-             "concat": torch.randn(T, 4, hw, hw, generator=g),
-             "vector": torch.randn(T, 896, generator=g).clamp(-1, 1)}
-        uc = {"crossattn": torch.zeros_like(c["crossattn"]), "concat": torch.zeros_like(c["concat"]),
-              "vector": c["vector"].clone()}
+        noise, c, uc = synth_inputs(dev, T, hw, hw, seed, cond)
+        x = noise * (1.0 + sig ** 2) ** 0.5
+        cpu = lambda d: {k: v.cpu() for k, v in d.items()}   # noqa: E731
         t0 = time.perf_counter()
         with torch.no_grad():
-            O.sampler_step(sd, O.KUBRIC, x, 700.0, 545.7, c, uc, T, ioi2, scale)
-        return time.perf_counter() - t0
+            ref = O.sampler_step(sd, O.KUBRIC, x.cpu(), sig, nxt, cpu(c), cpu(uc), T, ioi2, scale)
+        dt = time.perf_counter() - t0
+        loop = FusedEulerLoop(sampler, fd, noise.clone(), c, uc)
+        with loop:
+            loop.x.copy_(x)
+            loop.sig.copy_(torch.tensor([sig, nxt], device=dev))
+            loop.launch_step()
+        loop.close()
+        got = loop.x.detach().cpu().double()
+        rel = float((got - ref.double()).norm() / ref.double().norm())
+        return dt, rel
 
     hw, tf = 16, STEP_TFLOP[(32, 32)] * (16 * 16) / (32 * 32)    # FLOPs scale ~ with pixels here
-    dt = one(16)
+    dt, rel = one(16)
     if dt < 6.0:
         hw, tf = 32, STEP_TFLOP[(32, 32)]
-        dt = one(32)
+        dt, rel = one(32)
     tflops = tf / dt
-    return dict(value=tflops / STEP_TFLOP[(72, 128)], unit="steps/s", cores=cores, kind="port",
+    base = dict(value=tflops / STEP_TFLOP[(72, 128)], unit="steps/s", cores=cores, kind="port",
                 sample=f"1 EulerEDM step (UNet on 28 frames) at 14x{hw}x{hw} latents ~ {tf:.2f} TFLOP "
                        f"in {dt:.1f} s ({tflops:.2f} TFLOP/s fp32, {cores} threads), scaled to "
                        f"14x72x128 by algorithmic FLOPs ({STEP_TFLOP[(72, 128)]} TFLOP/step)",
-                measured_steps_per_s_at_sample=1.0 / dt)
+                measured_steps_per_s_at_sample=1.0 / dt,
+                reference_at_shape=REFERENCE_AT_SHAPE)
+    parity = dict(shape=[T, hw, hw, 4], config="BASELINE.json cfg0 (one EulerEDM step, CFG, 28-frame UNet)",
+                  sigma=sig, next_sigma=nxt, rel_l2=rel, tol=PARITY_TOL, ok=bool(rel <= PARITY_TOL),
+                  against="oracle/svd_unet_ref.py on the same weights and inputs (pinned to the reference "
+                          "at this shape by tests/test_oracle.py::test_oracle_full_width_cfg0_step...)")
+    return base, parity
+
+
+def sources_digest():
+    from gcd_amd.csrc import build as _b
+    return _b.sources_digest()
 
 
 def _pmc_traffic():
-    """HBM-side bytes per GEMM-family launch from the committed PMC passes of this same command
-    (counters cannot be read from inside the process; None if the profile is not shipped)."""
-    f = Path(__file__).resolve().parent / "profiles" / "r01v_hbm_traffic.json"
+    """HBM-side bytes per GEMM-family launch from the PMC passes of this same command (counters
+    cannot be read from inside the process): profiles/hbm_traffic_latest.json, written by
+    tools/pmc_traffic.py with the digest of the sources it was collected on.  Returns
+    (bytes_per_launch or None, note)."""
+    f = ROOT / "profiles" / "hbm_traffic_latest.json"
     try:
-        return json.loads(f.read_text())["gemm"]["bytes_per_launch"]
+        d = json.loads(f.read_text())
     except Exception:
-        return None
+        return None, "no profiles/hbm_traffic_latest.json shipped"
+    have, want = d.get("sources_digest"), sources_digest()
+    if have != want:
+        return None, (f"profiles/hbm_traffic_latest.json was collected on sources {have}, this build is "
+                      f"{want}: stale, not quoted (re-run tools/pmc_traffic.sh)")
+    return d["gemm"]["bytes_per_launch"], (f"{d.get('source', 'profiles/hbm_traffic_latest.json')}: rocprofv3 --pmc "
+                                           "FETCH_SIZE / WRITE_SIZE passes of this command on these sources "
+                                           "(FETCH x2 per the gfx950 note of MI355X_MICROARCH.md)")
 
 
 def main():
@@ -135,17 +209,29 @@ def main():
     ap.add_argument("--latent", type=str, default="72x128", help="latent HxW (default 72x128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of --steps steps each: the first is the reported one (driver "
+                         "contract), all of them feed timing_stats (median)")
     ap.add_argument("--dump-profile", type=str, default=None,
                     help="write the per-launch HIP-event table of the instrumented step (JSON)")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # self-launch: one rank per GPU under torch.distributed.run (what the driver does itself)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               str(Path(__file__).resolve())] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks "
-                         f"(WORLD_SIZE={world})")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product")
     dev = torch.device("cuda", local_rank)
@@ -166,7 +252,8 @@ def main():
     T = 14
     h, w = (int(v) for v in args.latent.split("x"))
     net = build_model(dev, seed=0)                      # same weights on every rank (replicas)
-    noise, c, uc = synth_inputs(dev, T, h, w, seed=100 + rank)   # a different clip per rank
+    cond = pose_conditioner(dev)
+    noise, c, uc = synth_inputs(dev, T, h, w, seed=100 + rank, cond=cond)   # a different clip per rank
     nsched = max(args.steps + args.warmup, 2)
     sampler = EulerEDMSampler(
         discretization_config={"target": "gcd_amd.discretizer.EDMDiscretization",
@@ -204,6 +291,15 @@ def main():
         wall = time.perf_counter() - t0
         ev_ms = e0.elapsed_time(e1)
         finite = bool(torch.isfinite(loop.x).all())
+        # further regions of the same length: spread of the measurement (the first one is `value`)
+        regions = [wall]
+        for r in range(1, max(1, args.repeats)):
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                loop.step(nwarm + r * args.steps + i)
+            barrier()
+            regions.append(time.perf_counter() - t1)
 
         # ---- instrumented eager step: per-launch HIP events on the launch stream ----
         prof = ops.start_profile()
@@ -230,14 +326,18 @@ def main():
         Path(args.dump_profile).write_text(json.dumps(table))
 
     # ---- aggregate over ranks ----
-    elapsed = torch.tensor([wall], device=dev, dtype=torch.float64)
+    elapsed = torch.tensor(regions, device=dev, dtype=torch.float64)
+    per_rank = [elapsed.clone()]
     if dist is not None:
+        per_rank = [torch.empty_like(elapsed) for _ in range(world)]
+        dist.all_gather(per_rank, elapsed)
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     t_gather0 = time.perf_counter()
     gathered = gather_clips(loop.x, dist)             # the one collective of the path
     torch.cuda.synchronize(dev)
     gather_ms = (time.perf_counter() - t_gather0) * 1e3
-    elapsed_s = float(elapsed.item())
+    elapsed_s = float(elapsed[0].item())
+    region_ms = sorted(float(v) * 1e3 / args.steps for v in elapsed.tolist())
 
     if rank == 0:
         ms_per_step = elapsed_s * 1e3 / args.steps
@@ -246,6 +346,7 @@ def main():
         gk = kinds.get("gemm", dict(flops=0.0, ms=1.0, launches=0))
         ak = kinds.get("attn_spatial", dict(flops=0.0, ms=1.0, launches=0))
         gemm_tflops = gk["flops"] / (gk["ms"] * 1e-3) / 1e12
+        traffic, traffic_note = _pmc_traffic()
         out = {
             "metric": "UNet denoise steps/sec, 14-frame 576x1024 SVD latents",
             "value": round(steps_per_s, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
@@ -260,8 +361,8 @@ def main():
                        "graph": sampler.use_graph},
             "roofline": {"bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": PEAK_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(gemm_tflops / PEAK_MFMA_TFLOPS, 4),
-                         "traffic": _pmc_traffic(), "traffic_unit": "bytes per launch (fabric-side: HBM + Infinity Cache)",
-                         "traffic_profile": "profiles/r01v_hbm_traffic.{txt,json}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_traffic.py; FETCH x2 per the gfx950 note of MI355X_MICROARCH.md), per shape: profiles/r01k_gemm_hbm_traffic.txt",
+                         "traffic": traffic, "traffic_unit": "bytes per launch (fabric-side: HBM + Infinity Cache)",
+                         "traffic_profile": traffic_note, "sources_digest": sources_digest(),
                          "kernel": "gemm_pp_kernel + gemm_f16_kernel (MFMA implicit-GEMM family: Linear, Conv2d 3x3/1x1, Conv3d (3,1,1))",
                          "launches_per_step": gk["launches"],
                          "algorithmic_tflop_per_step": round(gk["flops"] / 1e12, 3),
@@ -272,6 +373,12 @@ def main():
                 "kernel_ms_per_step": round(ak["ms"], 3), "launches_per_step": ak["launches"]},
             "frame_evals_per_s": round(steps_per_s * 2 * T, 2),
             "hip_event_ms_per_step_rank0": round(ev_ms / args.steps, 3),
+            "timing_stats": {"regions": len(region_ms), "steps_per_region": args.steps,
+                             "ms_per_step_sorted": [round(v, 3) for v in region_ms],
+                             "ms_per_step_median": round(region_ms[len(region_ms) // 2], 3),
+                             "reported_region": "first (max over ranks)"},
+            "per_rank_ms_per_step": [round(float(t[0]) * 1e3 / args.steps, 3) for t in per_rank],
+            "rccl_ranks": world if dist is not None else 0,
             "gather_ms": round(gather_ms, 3), "gathered_shape": list(gathered.shape),
             "output_finite": finite,
             "workspace_gib": round(net.engine.ws.nbytes() / 2 ** 30, 2),
@@ -279,9 +386,15 @@ def main():
         if step_tf is not None:
             out["step_tflops_per_gpu"] = round(step_tf * args.steps / elapsed_s, 2)
             out["step_frac_of_mfma_peak"] = round(step_tf * args.steps / elapsed_s / PEAK_MFMA_TFLOPS, 4)
+        parity_ok = True
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(net, T, seed=5)
+            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(net, sampler, fd, T, dev, 5, cond)
+            parity_ok = out["parity"]["ok"]
         print(json.dumps(out), flush=True)
+        if not parity_ok:
+            print(f"bench.py: PARITY FAILED: rel-L2 {out['parity']['rel_l2']:.3e} > {PARITY_TOL}",
+                  file=sys.stderr, flush=True)
+            sys.exit(3)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -42,6 +42,149 @@ class AbstractEmbModel(nn.Module):
         self.input_key = None
 
 
+def _disabled_train(self, mode=True):
+    """sgm/util.py `disabled_train`: frozen embedders never leave eval mode."""
+    return self
+
+
+def _expand_dims_like(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    while x.dim() != y.dim():
+        x = x.unsqueeze(-1)
+    return x
+
+
+class GeneralConditioner(nn.Module):
+    """Drop-in for `sgm.modules.encoders.modules.GeneralConditioner` (encoders/modules.py:84-208): the
+    `conditioner_config.target` socket of DiffusionEngine (diffusion.py:110-112).
+
+    Runs every embedder on `batch[embedder.input_key]` and assembles the sampler's conditioning
+    dict by output rank: 2-D -> `vector` (concatenated on dim 1: 3 x 256 sinusoid ids + the 128-d
+    camera-pose embedding = the 896 columns `label_emb` / `aux_label_emb` consume,
+    video_model.py:491-497), 3-D -> `crossattn` (dim 2), 4/5-D -> `concat` (dim 1).
+    `force_zero_embeddings` zeroes whole outputs by input key (how `sample_video` builds `uc`,
+    diffusion.py:522-524); `ucg_rate` drops rows at training time.  Same embedder attributes
+    (`is_trainable`, `ucg_rate`, `input_key[s]`, `legacy_ucg_val`), same `embedders.N.*` parameter
+    names, same errors."""
+
+    OUTPUT_DIM2KEYS = {2: "vector", 3: "crossattn", 4: "concat", 5: "concat"}
+    KEY2CATDIM = {"vector": 1, "crossattn": 2, "concat": 1}
+
+    def __init__(self, emb_models):
+        super().__init__()
+        import numpy as np
+        from .util import instantiate_from_config
+        embedders = []
+        for n, embconfig in enumerate(emb_models):
+            embedder = instantiate_from_config(embconfig)
+            assert isinstance(embedder, AbstractEmbModel), \
+                f"embedder model {embedder.__class__.__name__} has to inherit from AbstractEmbModel"
+            embedder.is_trainable = embconfig.get("is_trainable", False)
+            embedder.ucg_rate = embconfig.get("ucg_rate", 0.0)
+            if not embedder.is_trainable:
+                embedder.train = _disabled_train.__get__(embedder)
+                for param in embedder.parameters():
+                    param.requires_grad = False
+                embedder.eval()
+            if "input_key" in embconfig:
+                embedder.input_key = embconfig["input_key"]
+            elif "input_keys" in embconfig:
+                embedder.input_key = None
+                embedder.input_keys = embconfig["input_keys"]
+            else:
+                raise KeyError(f"need either 'input_key' or 'input_keys' for embedder "
+                               f"{embedder.__class__.__name__}")
+            embedder.legacy_ucg_val = embconfig.get("legacy_ucg_value", None)
+            if embedder.legacy_ucg_val is not None:
+                embedder.ucg_prng = np.random.RandomState()
+            embedders.append(embedder)
+        self.embedders = nn.ModuleList(embedders)
+
+    def possibly_get_ucg_val(self, embedder, batch):
+        assert embedder.legacy_ucg_val is not None
+        p, val = embedder.ucg_rate, embedder.legacy_ucg_val
+        for i in range(len(batch[embedder.input_key])):
+            if embedder.ucg_prng.choice(2, p=[1 - p, p]):
+                batch[embedder.input_key][i] = val
+        return batch
+
+    def forward(self, batch, force_zero_embeddings=None):
+        from contextlib import nullcontext
+        output = dict()
+        if force_zero_embeddings is None:
+            force_zero_embeddings = []
+        for embedder in self.embedders:
+            ctx = nullcontext if embedder.is_trainable else torch.no_grad
+            with ctx():
+                if getattr(embedder, "input_key", None) is not None:
+                    if embedder.legacy_ucg_val is not None:
+                        batch = self.possibly_get_ucg_val(embedder, batch)
+                    emb_out = embedder(batch[embedder.input_key])
+                elif hasattr(embedder, "input_keys"):
+                    emb_out = embedder(*[batch[k] for k in embedder.input_keys])
+            assert isinstance(emb_out, (torch.Tensor, list, tuple)), \
+                f"encoder outputs must be tensors or a sequence, but got {type(emb_out)}"
+            if not isinstance(emb_out, (list, tuple)):
+                emb_out = [emb_out]
+            for emb in emb_out:
+                out_key = self.OUTPUT_DIM2KEYS[emb.dim()]
+                if embedder.ucg_rate > 0.0 and embedder.legacy_ucg_val is None:
+                    keep = torch.bernoulli((1.0 - embedder.ucg_rate)
+                                           * torch.ones(emb.shape[0], device=emb.device))
+                    emb = _expand_dims_like(keep, emb) * emb      # per row of the batch = per frame
+                if getattr(embedder, "input_key", None) is not None and \
+                        embedder.input_key in force_zero_embeddings:
+                    emb = torch.zeros_like(emb)
+                if out_key in output:
+                    output[out_key] = torch.cat((output[out_key], emb), self.KEY2CATDIM[out_key])
+                else:
+                    output[out_key] = emb
+        return output
+
+    def get_unconditional_conditioning(self, batch_c, batch_uc=None, force_uc_zero_embeddings=None,
+                                       force_cond_zero_embeddings=None):
+        if force_uc_zero_embeddings is None:
+            force_uc_zero_embeddings = []
+        ucg_rates = []
+        for embedder in self.embedders:
+            ucg_rates.append(embedder.ucg_rate)
+            embedder.ucg_rate = 0.0
+        c = self(batch_c, force_cond_zero_embeddings)
+        uc = self(batch_c if batch_uc is None else batch_uc, force_uc_zero_embeddings)
+        for embedder, rate in zip(self.embedders, ucg_rates):
+            embedder.ucg_rate = rate
+        return c, uc
+
+
+class IdentityEncoder(AbstractEmbModel):
+    """encoders/modules.py:290-295."""
+
+    def encode(self, x):
+        return x
+
+    def forward(self, x):
+        return x
+
+
+class FrozenOpenCLIPImagePredictionEmbedder(AbstractEmbModel):
+    """Frame-axis plumbing around the CLIP image tower (encoders/modules.py:1117-1136): the tower
+    itself (`open_clip_embedding_config`, third-party ViT-H/14 weights) stays whatever the config
+    names — SURVEY.md §8(f)-3 keeps it on PyTorch-ROCm; this class only does the
+    `(b t) d -> (b s) t d` rearrange that produces the single-token `crossattn` context."""
+
+    def __init__(self, open_clip_embedding_config, n_cond_frames: int, n_copies: int):
+        super().__init__()
+        from .util import instantiate_from_config
+        self.n_cond_frames = n_cond_frames
+        self.n_copies = n_copies
+        self.open_clip = instantiate_from_config(open_clip_embedding_config)
+
+    def forward(self, vid):
+        vid = self.open_clip(vid)
+        d = vid.shape[-1]
+        vid = vid.reshape(-1, self.n_cond_frames, d)                     # (b t) d -> b t d
+        return vid.repeat_interleave(self.n_copies, dim=0)               # b t d -> (b s) t d
+
+
 class SphericalEmbedder(AbstractEmbModel):
     """(d_azimuth, d_elevation, d_radius) -> [cos, sin](az * {1,2,4}), [cos, sin](el * {1,2,4}), r
     -> Linear(13, embed_dim)   (encoders/modules.py:247-287)."""

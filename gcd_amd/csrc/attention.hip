@@ -706,12 +706,11 @@ extern "C" int gcd_attn_temporal_f16(const void* qkv, int64_t ld, void* out, int
   const int64_t blocks = (nprob + TPROB - 1) / TPROB;
   GCD_CHECK_ARG(blocks < (1ll << 31), "gcd_attn_temporal_f16: grid too large");
   const int smem = 2 * TPROB * TP_STRIDE(T);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static GcdPerDeviceOnce attr_once;
+  if (attr_once.first_use()) {
     GCD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_temporal_kernel,
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       2 * TPROB * TP_STRIDE(16)));
-    attr_set = true;
   }
   hipLaunchKernelGGL(attn_temporal_kernel, dim3((unsigned)blocks), dim3(256), smem,
                      (hipStream_t)stream, (const f16*)qkv, ld, (f16*)out, ldo, nprob, T, HW, heads);

@@ -40,7 +40,23 @@ def _digest() -> str:
     return h.hexdigest()
 
 
-def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -> Path:
+def sources_digest() -> str:
+    """Content hash of everything that decides which kernels a sampler step launches and how: the
+    HIP sources + headers + flags and the host-side engine.  tools/pmc_traffic.py stamps a PMC
+    profile with it and bench.py quotes `roofline.traffic` only while it matches."""
+    h = hashlib.sha256(_digest().encode())
+    for f in ("engine.py", "ops.py", "sampling.py"):
+        h.update((PKG / f).read_bytes())
+    return h.hexdigest()[:16]
+
+
+def build(force: bool = False, save_temps: bool = False, verbose: bool = True,
+          ablation: bool = False) -> Path:
+    """ablation=True builds tools/libgcd_amd_ablate.so instead: the same sources with
+    -DGCD_ABLATION_BUILD, which adds the wrong-by-design kernel variants tools/gemm_bench times
+    (GCD_TUNE_GEMM_IMPL >= 32).  The product library never contains them."""
+    if ablation:
+        return _build_ablation(verbose)
     digest = _digest()
     if not force and LIB.exists() and STAMP.exists() and STAMP.read_text().strip() == digest:
         return LIB
@@ -69,6 +85,30 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -
     return LIB
 
 
+def _build_ablation(verbose: bool) -> Path:
+    hipcc = _hipcc()
+    objdir = CSRC / "build" / "ablate"
+    objdir.mkdir(parents=True, exist_ok=True)
+    out = ROOT / "tools" / "libgcd_amd_ablate.so"
+    procs = []
+    for src in SOURCES:
+        obj = objdir / (src + ".o")
+        cmd = [hipcc, *FLAGS, "-DGCD_ABLATION_BUILD", "-c", str(CSRC / src), "-o", str(obj)]
+        if verbose:
+            print("[gcd_amd.build]", " ".join(cmd), flush=True)
+        procs.append((src, obj, subprocess.Popen(cmd, cwd=str(objdir))))
+    objs = []
+    for src, obj, pr in procs:
+        if pr.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+        objs.append(str(obj))
+    subprocess.check_call([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", str(out)])
+    return out
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv)
-    print(LIB)
+    if "--ablation" in sys.argv:
+        print(build(ablation=True))
+    else:
+        build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv)
+        print(LIB)

@@ -40,6 +40,22 @@ void gcd_set_error(const char* fmt, ...);
 
 #define GCD_CHECK_LAUNCH() GCD_CHECK_HIP(hipGetLastError())
 
+// hipFuncSetAttribute (the > 64 KB dynamic-LDS opt-in) is a per-DEVICE property of a kernel: a
+// launcher keeps one of these (static) and sets the attribute the first time it runs on each device
+// ordinal, so a process that drives several GPUs does not launch un-opted kernels on the second one.
+struct GcdPerDeviceOnce {
+  unsigned long long seen[4] = {0, 0, 0, 0};
+  bool first_use() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) return true;
+    d &= 255;
+    const unsigned long long bit = 1ull << (d & 63);
+    const bool was = (seen[d >> 6] & bit) != 0;
+    seen[d >> 6] |= bit;
+    return !was;
+  }
+};
+
 // ---- device helpers ----------------------------------------------------------------------------
 // Asynchronous 16-byte global -> LDS copy (global_load_lds_dwordx4).  The LDS destination is
 // wave-uniform base + lane*16, the global source address is per lane.

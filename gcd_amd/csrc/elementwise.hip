@@ -4,7 +4,7 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------
-// y[M,N] = [y +] act_out( act_in(x[M,K]) @ W[N,K]^T + b )   fp32, M <= 32.
+// y[M,N] = [y +] act_out( act_in(x[M,K]) @ W[N,K]^T + b )   fp32, any M (32 rows per launch).
 // A skinny GEMM that only has to stream W (up to 190 MB for the 44 stacked emb_layers) at HBM rate:
 // workgroup = 4 waves x 4 output columns; x is staged (activation applied) through LDS in K chunks
 // of 256; a lane owns (column lane >> 4, k-slot lane & 15): the 16 lanes of a column read 256
@@ -90,18 +90,25 @@ extern "C" int gcd_linear_smallm_f32(const float* x, int64_t ldx, const float* W
                                      float* y, int64_t ldy, int M, int N, int K, int act_flags,
                                      void* stream) {
   GCD_CHECK_ARG(x && W && y, "gcd_linear_smallm_f32: null pointer");
-  GCD_CHECK_ARG(M >= 1 && M <= 32, "gcd_linear_smallm_f32: M=%d (supported 1..32)", M);
+  GCD_CHECK_ARG(M >= 1, "gcd_linear_smallm_f32: M=%d (must be >= 1)", M);
   GCD_CHECK_ARG(N >= 1 && K >= 4 && K % 4 == 0 && ldx % 4 == 0,
                 "gcd_linear_smallm_f32: N=%d K=%d ldx=%lld (K, ldx must be multiples of 4)", N, K,
                 (long long)ldx);
   const dim3 grid((N + 15) / 16), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (M <= 4)
-    hipLaunchKernelGGL(linear_smallm_kernel<4>, grid, block, 0, s, x, ldx, W, b, y, ldy, M, N, K, act_flags);
-  else if (M <= 16)
-    hipLaunchKernelGGL(linear_smallm_kernel<16>, grid, block, 0, s, x, ldx, W, b, y, ldy, M, N, K, act_flags);
-  else
-    hipLaunchKernelGGL(linear_smallm_kernel<32>, grid, block, 0, s, x, ldx, W, b, y, ldy, M, N, K, act_flags);
+  // any M: rows go through the kernel 32 at a time (two clips under CFG are 56 frames; the weights
+  // of one launch are a few MB and stay in L2 / Infinity Cache for the next chunk)
+  for (int m0 = 0; m0 < M; m0 += 32) {
+    const int mc = M - m0 < 32 ? M - m0 : 32;
+    const float* xc = x + (int64_t)m0 * ldx;
+    float* yc = y + (int64_t)m0 * ldy;
+    if (mc <= 4)
+      hipLaunchKernelGGL(linear_smallm_kernel<4>, grid, block, 0, s, xc, ldx, W, b, yc, ldy, mc, N, K, act_flags);
+    else if (mc <= 16)
+      hipLaunchKernelGGL(linear_smallm_kernel<16>, grid, block, 0, s, xc, ldx, W, b, yc, ldy, mc, N, K, act_flags);
+    else
+      hipLaunchKernelGGL(linear_smallm_kernel<32>, grid, block, 0, s, xc, ldx, W, b, yc, ldy, mc, N, K, act_flags);
+  }
   GCD_CHECK_LAUNCH();
   return 0;
 }

@@ -268,12 +268,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmK p) {
 template <int BM, int BN, int WM, int WN, int MODE>
 static int launch_gemm(const GemmK& k, hipStream_t s) {
   constexpr int smem = 2 * (BM + BN) * 128;
-  static bool attr_set = false;
+  static GcdPerDeviceOnce attr_once;
   auto fn = gemm_f16_kernel<BM, BN, WM, WN, MODE>;
-  if (!attr_set) {
+  if (attr_once.first_use()) {
     GCD_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       smem));
-    attr_set = true;
   }
   GemmK kk = k;
   kk.tiles_m = (k.M + BM - 1) / BM;
@@ -301,6 +300,45 @@ static int dispatch_tile(const GemmK& k, hipStream_t s) {
   if (use160 && ((tiles128 <= 320 && impl != 5) || impl == 6)) return launch_gemm<64, 160, 32, 80, MODE>(k, s);
   if (use160) return launch_gemm<128, 160, 64, 80, MODE>(k, s);
   return launch_gemm<128, 128, 64, 64, MODE>(k, s);
+}
+
+// Implicit-GEMM geometry of a descriptor (conv3x3: pad 1 / stride 1-2 / fused x2 upsample /
+// asymmetric pad; temporal3: clips of T frames x HW tokens).  0 = fine, else the error is set.
+static int validate_geometry(const gcd_gemm_desc* d) {
+  switch (d->mode) {
+    case GCD_GEMM_PLAIN:
+      return 0;
+    case GCD_GEMM_CONV3X3:
+      GCD_CHECK_ARG(d->zero_page, "gcd_gemm_f16: conv mode needs a zero page");
+      GCD_CHECK_ARG(d->Cin > 0 && d->Cin % 32 == 0 && d->K == 9 * d->Cin,
+                    "gcd_gemm_f16: conv3x3 needs Cin %% 32 == 0 and K == 9*Cin (Cin=%d K=%d)",
+                    d->Cin, d->K);
+      GCD_CHECK_ARG(d->stride == 1 || d->stride == 2, "gcd_gemm_f16: stride %d", d->stride);
+      GCD_CHECK_ARG(d->Ho > 0 && d->Wo > 0 && d->M % (d->Ho * d->Wo) == 0,
+                    "gcd_gemm_f16: M=%d is not frames*Ho*Wo (%dx%d)", d->M, d->Ho, d->Wo);
+      if (d->upsample)
+        GCD_CHECK_ARG(d->stride == 1 && d->Ho == 2 * d->Hi && d->Wo == 2 * d->Wi,
+                      "gcd_gemm_f16: fused upsample needs Ho=2Hi, Wo=2Wi, stride 1");
+      else if (d->asym_pad)
+        GCD_CHECK_ARG(d->stride == 2 && d->Ho == d->Hi / 2 && d->Wo == d->Wi / 2,
+                      "gcd_gemm_f16: asym_pad needs stride 2 and Ho = Hi/2, Wo = Wi/2 (%dx%d -> %dx%d)",
+                      d->Hi, d->Wi, d->Ho, d->Wo);
+      else
+        GCD_CHECK_ARG(d->Ho == (d->Hi - 1) / d->stride + 1 && d->Wo == (d->Wi - 1) / d->stride + 1,
+                      "gcd_gemm_f16: conv3x3 pad-1 geometry mismatch (%dx%d -> %dx%d, stride %d)",
+                      d->Hi, d->Wi, d->Ho, d->Wo, d->stride);
+      return 0;
+    case GCD_GEMM_TEMPORAL3:
+      GCD_CHECK_ARG(d->zero_page, "gcd_gemm_f16: temporal mode needs a zero page");
+      GCD_CHECK_ARG(d->Cin > 0 && d->Cin % 32 == 0 && d->K == 3 * d->Cin,
+                    "gcd_gemm_f16: temporal3 needs Cin %% 32 == 0 and K == 3*Cin");
+      GCD_CHECK_ARG(d->T > 0 && d->HW > 0 && d->M % (d->T * d->HW) == 0,
+                    "gcd_gemm_f16: M=%d is not clips*T*HW (T=%d HW=%d)", d->M, d->T, d->HW);
+      return 0;
+    default:
+      gcd_set_error("gcd_gemm_f16: unknown mode %d", d->mode);
+      return 2;
+  }
 }
 
 extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
@@ -405,6 +443,10 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
                 "gcd_gemm_f16: K=%d (Cin=%d) needs the ping-pong kernel, which the shape or "
                 "GCD_TUNE_GEMM_IMPL=%d rules out", d->K, d->Cin, impl);
 
+  // mode-specific geometry, checked BEFORE any kernel choice (split-K included): a malformed conv /
+  // temporal descriptor must come back as an argument error, never reach a gather
+  if (const int rc = validate_geometry(d)) return rc;
+
   // split-K: few 256x320 tiles (<= 96 of 256 CUs) and a long K — the 3x3 convs of the 9x16 level
   if (d->workspace && !d->ln_out16 && d->out_kind != GCD_OUT_GEGLU && (impl == 0 || impl == 7) &&
       gcd_gemm_pp_supported(k, d->mode) && d->N >= 160 && d->N % 4 == 0) {
@@ -413,7 +455,6 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
     if (splitk > 4) splitk = 4;
     if (tiles <= 96 && splitk >= 2 && d->K / splitk >= 1920 &&
         d->workspace_bytes >= (int64_t)splitk * d->M * d->N * 4 && ((uintptr_t)d->workspace & 15) == 0) {
-      if (d->mode != GCD_GEMM_PLAIN) GCD_CHECK_ARG(d->zero_page, "gcd_gemm_f16: conv mode needs a zero page");
       return gcd_gemm_pp_launch_splitk(k, d->mode, splitk, (float*)d->workspace, s);
     }
   }
@@ -422,40 +463,12 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
     case GCD_GEMM_PLAIN:
       if (use_pp) return gcd_gemm_pp_launch(k, d->mode, s);
       return dispatch_tile<GCD_GEMM_PLAIN>(k, s);
-    case GCD_GEMM_CONV3X3: {
-      GCD_CHECK_ARG(d->zero_page, "gcd_gemm_f16: conv mode needs a zero page");
-      GCD_CHECK_ARG(d->Cin > 0 && d->Cin % 32 == 0 && d->K == 9 * d->Cin,
-                    "gcd_gemm_f16: conv3x3 needs Cin %% 32 == 0 and K == 9*Cin (Cin=%d K=%d)",
-                    d->Cin, d->K);
-      GCD_CHECK_ARG(d->stride == 1 || d->stride == 2, "gcd_gemm_f16: stride %d", d->stride);
-      GCD_CHECK_ARG(d->Ho > 0 && d->Wo > 0 && d->M % (d->Ho * d->Wo) == 0,
-                    "gcd_gemm_f16: M=%d is not frames*Ho*Wo (%dx%d)", d->M, d->Ho, d->Wo);
-      if (d->upsample)
-        GCD_CHECK_ARG(d->stride == 1 && d->Ho == 2 * d->Hi && d->Wo == 2 * d->Wi,
-                      "gcd_gemm_f16: fused upsample needs Ho=2Hi, Wo=2Wi, stride 1");
-      else if (d->asym_pad)
-        GCD_CHECK_ARG(d->stride == 2 && d->Ho == d->Hi / 2 && d->Wo == d->Wi / 2,
-                      "gcd_gemm_f16: asym_pad needs stride 2 and Ho = Hi/2, Wo = Wi/2 (%dx%d -> %dx%d)",
-                      d->Hi, d->Wi, d->Ho, d->Wo);
-      else
-        GCD_CHECK_ARG(d->Ho == (d->Hi - 1) / d->stride + 1 && d->Wo == (d->Wi - 1) / d->stride + 1,
-                      "gcd_gemm_f16: conv3x3 pad-1 geometry mismatch (%dx%d -> %dx%d, stride %d)",
-                      d->Hi, d->Wi, d->Ho, d->Wo, d->stride);
+    case GCD_GEMM_CONV3X3:
       if (use_pp) return gcd_gemm_pp_launch(k, d->mode, s);
       return dispatch_tile<GCD_GEMM_CONV3X3>(k, s);
-    }
-    case GCD_GEMM_TEMPORAL3: {
-      GCD_CHECK_ARG(d->zero_page, "gcd_gemm_f16: temporal mode needs a zero page");
-      GCD_CHECK_ARG(d->Cin > 0 && d->Cin % 32 == 0 && d->K == 3 * d->Cin,
-                    "gcd_gemm_f16: temporal3 needs Cin %% 32 == 0 and K == 3*Cin");
-      GCD_CHECK_ARG(d->T > 0 && d->HW > 0 && d->M % (d->T * d->HW) == 0,
-                    "gcd_gemm_f16: M=%d is not clips*T*HW (T=%d HW=%d)", d->M, d->T, d->HW);
+    default:   // GCD_GEMM_TEMPORAL3 (validate_geometry rejected anything else)
       if (use_pp) return gcd_gemm_pp_launch(k, d->mode, s);
       return dispatch_tile<GCD_GEMM_TEMPORAL3>(k, s);
-    }
-    default:
-      gcd_set_error("gcd_gemm_f16: unknown mode %d", d->mode);
-      return 2;
   }
 }
 

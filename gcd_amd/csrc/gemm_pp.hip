@@ -414,12 +414,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
 
 template <int MODE, int VAR = 0>
 int launch_pp(const GemmK& k, hipStream_t s) {
-  static bool attr_set = false;
+  static GcdPerDeviceOnce attr_once;
   auto fn = gemm_pp_kernel<MODE, VAR>;
-  if (!attr_set) {
+  if (attr_once.first_use()) {
     GCD_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       PP_SMEM_LAUNCH));
-    attr_set = true;
   }
   GemmK kk = k;
   kk.tiles_m = (k.M + PP_BM - 1) / PP_BM;
@@ -471,12 +470,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmK p, const
 
 template <int MODE>
 int launch_pp_splitk(const GemmK& k, int splitk, float* ws, hipStream_t s) {
-  static bool attr_set = false;
+  static GcdPerDeviceOnce attr_once;
   auto fn = gemm_pp_kernel<MODE, 16384>;
-  if (!attr_set) {
+  if (attr_once.first_use()) {
     GCD_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       PP_SMEM_LAUNCH));
-    attr_set = true;
   }
   GemmK kk = k;
   kk.tiles_m = (k.M + PP_BM - 1) / PP_BM;
@@ -525,7 +523,11 @@ bool gcd_gemm_pp_supported(const GemmK& k, int mode) {
 }
 
 int gcd_gemm_pp_launch(const GemmK& k, int mode, hipStream_t s) {
-  const int var = gcd_tune_get(GCD_TUNE_GEMM_IMPL) - 32;   // 32 + VAR: ablation builds (PLAIN only)
+#ifdef GCD_ABLATION_BUILD
+  // Wrong-by-design ablation instantiations (no DMA / no LDS reads / no stores ...): compiled only
+  // into tools/libgcd_amd_ablate.so (`python -m gcd_amd.csrc.build --ablation`) for tools/gemm_bench,
+  // never into the product library gcd_amd/libgcd_amd.so.
+  const int var = gcd_tune_get(GCD_TUNE_GEMM_IMPL) - 32;   // 32 + VAR (PLAIN only)
   if (var > 0 && mode == GCD_GEMM_PLAIN) {
     switch (var) {
       case 1: return launch_pp<GCD_GEMM_PLAIN, 1>(k, s);
@@ -546,6 +548,7 @@ int gcd_gemm_pp_launch(const GemmK& k, int mode, hipStream_t s) {
       default: break;
     }
   }
+#endif
   // More tiles than CUs: 256 persistent workgroups walk the tiles (saves the per-workgroup launch /
   // teardown, 6-7 % on the K = 320 / 640 shapes); otherwise one workgroup per tile.
   const int64_t tiles = (int64_t)((k.M + PP_BM - 1) / PP_BM) * ((k.N + PP_BN - 1) / PP_BN);

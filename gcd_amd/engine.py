@@ -117,6 +117,17 @@ class UNetEngine:
         # epilogue pays for it in VALU and 8-byte fp16 stores), so it is off unless GCD_FUSE_LN=1.
         self.fuse_layernorm = os.environ.get("GCD_FUSE_LN", "0") == "1"
         self.taps: Optional[dict] = None   # debug: name -> NCHW fp32 clone of every block output
+        self._side_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+    def side_stream(self, device) -> "torch.cuda.Stream":
+        """ONE side stream per (engine, device) for the fused sampling loops: a fresh stream per
+        sampler call would walk through torch's 32-stream pool and pin a split-K scratch (84 MB,
+        keyed by stream) for each of them."""
+        idx = torch.device(device).index or 0
+        s = self._side_streams.get(idx)
+        if s is None:
+            s = self._side_streams[idx] = torch.cuda.Stream(device=device)
+        return s
 
     # ------------------------------------------------------------------------------------------
     def invalidate(self) -> None:
@@ -302,7 +313,7 @@ class UNetEngine:
         return y
 
     def _mlp_small(self, x, m, out=None, accumulate=False):
-        """Linear -> SiLU -> Linear on [N <= 32, K] fp32 rows."""
+        """Linear -> SiLU -> Linear on [N, K] fp32 rows (any N: gcd_linear_smallm_f32 chunks by 32)."""
         ws = self.ws
         n = x.shape[0]
         hid = ws.alloc((n, m["w0"].shape[0]), torch.float32)
@@ -497,7 +508,10 @@ class UNetEngine:
         in-place edits bump torch's version counter and miss."""
         P = self.packed
         N, T = st["N"], st["T"]
-        key = (context_src._version, tuple(context_src.shape), context_src.dtype, N, T)
+        # inference-mode tensors have no version counter (reading _version raises): they cannot be
+        # edited in place behind our back, so identity alone is the key there
+        ver = -1 if context_src.is_inference() else context_src._version
+        key = (ver, tuple(context_src.shape), context_src.dtype, N, T)
         hit = P.get("ca_cache")
         if hit is not None and hit[0] is context_src and hit[1] == key:
             return hit[2]
@@ -550,6 +564,13 @@ class UNetEngine:
             alphas=None):
         """x: [nx, Cx, H, W] fp32 (nx == N, or N == 2*nx for the CFG-duplicated fused path with
         `concat` [N, Cc, H, W] and per-frame `c_in` [N]); writes out_nchw [N, out_ch, H, W] fp32."""
+        if x.device.index is not None and x.device.index != torch.cuda.current_device():
+            # kernels launch on the current device's current stream: make the tensors' device current
+            with torch.cuda.device(x.device):
+                return self.run(x, concat, c_in, timesteps, context, y, T, image_only_indicator,
+                                out_nchw, alphas)
+        if self.packed is not None and self._device() != x.device:
+            raise _lib.GcdError(f"VideoUNet parameters are on {self._device()} but the input is on {x.device}")
         P, ws, u = self.packed, self.ws, self.unet
         N = timesteps.shape[0]
         H, W = x.shape[-2:]

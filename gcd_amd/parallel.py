@@ -7,7 +7,7 @@ The only exchange is collecting the per-rank results: one all-gather (RCCL over 
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import Callable, List, Optional, Sequence
 
 import torch
 
@@ -43,15 +43,23 @@ def gather_ragged_clips(local: List[torch.Tensor], num_clips: int, dist=None,
     if per_rank == 0:
         return []
     proto = local[0] if local else None
-    shape = torch.tensor(list(proto.shape) if proto is not None else [0],
-                         dtype=torch.int64, device="cpu")
-    # every rank with >= 1 clip has the same clip shape; rank 0 always has one when num_clips > 0
-    shapes = [None] * world
-    dist.all_gather_object(shapes, shape.tolist(), group=group)
-    clip_shape = next(s for s in shapes if s != [0])
-    ref = proto if proto is not None else None
-    dev = ref.device if ref is not None else torch.device("cpu")
-    dtype = ref.dtype if ref is not None else torch.float32
+    # exchange shape, dtype and device TYPE: a rank that holds no clip must still contribute a pad
+    # tensor of the same dtype on the same kind of device as everybody else, or the all-gather
+    # errors (gloo) / hangs (RCCL)
+    meta = None if proto is None else (tuple(proto.shape), str(proto.dtype).replace("torch.", ""),
+                                       proto.device.type)
+    metas = [None] * world
+    dist.all_gather_object(metas, meta, group=group)
+    clip_shape, dtype_name, dev_type = next(m for m in metas if m is not None)
+    assert all(m is None or tuple(m) == (clip_shape, dtype_name, dev_type) for m in metas), \
+        f"ranks disagree on the clip shape / dtype / device: {metas}"
+    dtype = getattr(torch, dtype_name)
+    if proto is not None:
+        dev = proto.device
+    elif dev_type == "cuda":
+        dev = torch.device("cuda", torch.cuda.current_device())
+    else:
+        dev = torch.device(dev_type)
     stacked = torch.zeros((per_rank,) + tuple(clip_shape), dtype=dtype, device=dev)
     for i, t in enumerate(local):
         stacked[i] = t
@@ -61,3 +69,35 @@ def gather_ragged_clips(local: List[torch.Tensor], num_clips: int, dist=None,
         for j, clip in enumerate(clips_for_rank(num_clips, r, world)):
             out[clip] = allr[r, j]
     return out
+
+
+def sample_clips(sample_one: Callable[[int, torch.Generator], torch.Tensor], num_clips: int,
+                 dist=None, group=None, base_seed: int = 0, device=None,
+                 gather: bool = True) -> List[Optional[torch.Tensor]]:
+    """Sharded-clip driver: the multi-GPU shape of the reference's evaluation loop
+    (scripts/test.py:1051-1090 — one process + one model replica per GPU, examples strided over the
+    workers, no communication while sampling).
+
+    Rank r runs `sample_one(clip_index, generator)` for clips r, r + world, r + 2 world, ...; the
+    generator is seeded by `base_seed + clip_index`, so a clip's noise — and therefore its result —
+    does not depend on how many GPUs the job runs on.  With `gather`, one all-gather (RCCL over xGMI
+    / gloo) after the loop returns every clip's result on every rank, in clip order; otherwise each
+    rank gets its own clips in place and None elsewhere.
+
+    `sample_one` is typically
+        lambda i, g: sampler(denoiser_i, torch.randn(shape, generator=g, device=dev), cond_i, uc_i)
+    """
+    world = 1 if dist is None or not dist.is_initialized() else dist.get_world_size(group)
+    rank = 0 if world == 1 else dist.get_rank(group)
+    mine = clips_for_rank(num_clips, rank, world)
+    local = []
+    for i in mine:
+        g = torch.Generator(device=device) if device is not None else torch.Generator()
+        g.manual_seed(base_seed + i)
+        local.append(sample_one(i, g))
+    if not gather:
+        out: List[Optional[torch.Tensor]] = [None] * num_clips
+        for i, t in zip(mine, local):
+            out[i] = t
+        return out
+    return gather_ragged_clips(local, num_clips, dist, group)

@@ -189,10 +189,13 @@ class VideoDecoder(nn.Module):
     def forward(self, z: torch.Tensor, timesteps: Optional[int] = None, skip_video: bool = False,
                 **kwargs) -> torch.Tensor:
         """z (N, z_channels, h, w) -> (N, out_ch, 8h, 8w) for ch_mult of length 4; the N frames are
-        `N // timesteps` clips of `timesteps` frames (decode_first_stage passes the chunk length,
-        diffusion.py:243-244)."""
+        `N // timesteps` clips of `timesteps` frames.  `DiffusionEngine.decode_first_stage` passes
+        `timesteps = len(chunk)` only to decoders that pass its `isinstance(..., VideoDecoder)` test
+        against the reference class (diffusion.py:242-245); called without it — as it calls this
+        drop-in — the chunk is taken as one clip, i.e. the very value the reference would have
+        passed, so the config-only swap needs no edit there."""
         if skip_video:
             raise NotImplementedError("gcd_amd VideoDecoder: skip_video=True")
         if timesteps is None:
-            raise TypeError("VideoDecoder.forward needs timesteps (frames per clip)")
+            timesteps = z.shape[0]
         return self.engine.forward(z, int(timesteps))

@@ -133,7 +133,7 @@ int gcd_gemm_f16(const gcd_gemm_desc* desc, void* stream);
  * automatic kernel choice lands on the 256x320 ping-pong kernel and N == 320), else 0.          */
 int gcd_gemm_ln_fusable(int M, int N, int K, int mode);
 
-/* y[M,N] (fp32) = [y +] act_out( act_in(x[M,K]) @ W[N,K]^T + b ), fp32 weights, M <= 32.
+/* y[M,N] (fp32) = [y +] act_out( act_in(x[M,K]) @ W[N,K]^T + b ), fp32 weights, any M >= 1 (rows are processed 32 at a time).
  * act flags: bit0 = SiLU on input, bit1 = SiLU on output, bit2 = accumulate into y.
  * Replaces the tiny per-frame MLPs: video_model.py:155-200,485-497 (time/label/aux embeds),
  * openaimodel.py:287-293 (emb_layers), video_attention.py:216-222 (time_pos_embed),

@@ -353,12 +353,15 @@ def sampler_step(sd: SD, cfg: UNetConfig, x: torch.Tensor, sigma: float, sigma_n
 
 def sample_loop(sd: SD, cfg: UNetConfig, noise: torch.Tensor, c: dict, uc: dict, T: int,
                 num_steps: int, sigma_max: float = 700.0, max_scale: float = 1.5,
-                min_scale: float = 1.0, trace: Optional[list] = None) -> torch.Tensor:
+                min_scale: float = 1.0, trace: Optional[list] = None,
+                ioi2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """EDMSampler.__call__ (sampling.py:123-144) fed the way DiffusionEngine.sample_video does
-    (diffusion.py:522-543): image_only_indicator zeros(2B, T) after repeat_interleave(2)."""
+    (diffusion.py:522-543): image_only_indicator (2B, T) = batch value after repeat_interleave(2),
+    zeros unless given."""
     sigmas = edm_sigmas(num_steps, sigma_max=sigma_max)
     x = noise * torch.sqrt(1.0 + sigmas[0] ** 2.0)                         # sampling.py:54
-    ioi2 = torch.zeros(2 * noise.shape[0] // T, T)
+    if ioi2 is None:
+        ioi2 = torch.zeros(2 * noise.shape[0] // T, T)
     scale = guider_scale(T, max_scale, min_scale)
     for i in range(len(sigmas) - 1):
         x = sampler_step(sd, cfg, x, float(sigmas[i]), float(sigmas[i + 1]), c, uc, T, ioi2, scale)
@@ -392,3 +395,48 @@ def concat_timestep_embed(v: torch.Tensor, outdim: int = 256) -> torch.Tensor:
         v = v[:, None]
     b, d = v.shape
     return timestep_embedding(v.reshape(-1), outdim).reshape(b, d * outdim)
+
+
+def construct_trajectory(start, end, trajectory: str, T: int, move_time: int):
+    """sgm/data/common.py:450-479: the source camera rests at `start`; the destination camera goes
+    from `start` to `end` over the first `move_time` frames, then rests at `end`."""
+    start = torch.as_tensor(start, dtype=torch.float32)
+    end = torch.as_tensor(end, dtype=torch.float32)
+    src = start[None].repeat(T, 1)
+    dst = end[None].repeat(T, 1)
+    for t in range(max(0, move_time)):
+        if trajectory == "interpol_linear":
+            a = t / move_time
+        elif trajectory == "interpol_sine":
+            a = (1.0 - math.cos(t / move_time * math.pi)) / 2.0
+        else:
+            raise ValueError(f"Unknown trajectory: {trajectory}")
+        dst[t] = start * (1.0 - a) + end * a
+    return src, dst
+
+
+def scaled_relative_angles(az_deg: float, el_deg: float, r_m: float, T: int = 14,
+                           trajectory: str = "interpol_linear", move_time: int = 13) -> torch.Tensor:
+    """scripts/eval_utils.py:235-245: (dst - src) per frame, angles in radians."""
+    src, dst = construct_trajectory([0.0, 0.0, 0.0], [az_deg, el_deg, r_m], trajectory, T, move_time)
+    rel = dst - src
+    rel[:, 0] *= math.pi / 180.0
+    rel[:, 1] *= math.pi / 180.0
+    return rel
+
+
+def general_conditioner(embedded: Sequence[Tuple[str, torch.Tensor]],
+                        force_zero: Sequence[str] = ()) -> Dict[str, torch.Tensor]:
+    """GeneralConditioner.forward (encoders/modules.py:133-188) over already-embedded tensors:
+    `embedded` = [(input_key, embedder output)] in embedder order.  Rank 2 -> 'vector' (cat dim 1),
+    rank 3 -> 'crossattn' (cat dim 2), rank 4/5 -> 'concat' (cat dim 1); outputs whose input key is
+    in `force_zero` are replaced by zeros (how sample_video builds uc, diffusion.py:522-524)."""
+    dim2key = {2: "vector", 3: "crossattn", 4: "concat", 5: "concat"}
+    catdim = {"vector": 1, "crossattn": 2, "concat": 1}
+    out: Dict[str, torch.Tensor] = {}
+    for key, emb in embedded:
+        k = dim2key[emb.dim()]
+        if key in force_zero:
+            emb = torch.zeros_like(emb)
+        out[k] = torch.cat((out[k], emb), catdim[k]) if k in out else emb
+    return out

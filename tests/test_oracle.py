@@ -119,3 +119,25 @@ def test_embedders_against_reference_if_mounted():
         ref = net(x, ts, context=ctx, y=y, num_video_frames=2, image_only_indicator=ioi)
         mine = O.unet_forward(sd, cfg, x, ts, ctx, y, 2, ioi)
     assert rel_l2(mine, ref) < 2e-5
+
+
+def test_oracle_full_width_cfg0_step_vs_reference_golden():
+    """BASELINE.json cfg0 at the real width: one EulerEDM sampler_step of the 1.53 B-parameter Kubric
+    network on a 14 x 32 x 32 x 4 latent — the oracle restatement against the reference plugin stack's
+    own result (oracle/make_golden_fullres.py).  Pins the oracle at the shape bench.py's parity leg
+    and cpu_baseline use it."""
+    g = torch.load(GOLD / "step_kubric_32x32.pt")
+    from gcd_amd.video_model import VideoUNet
+    with torch.device("meta"):
+        shapes = {k: tuple(v.shape) for k, v in VideoUNet(**O.KUBRIC.as_reference_kwargs()).state_dict().items()}
+    sd = weights.synth_state_dict(shapes, g["salt"])
+    T, h, w = g["T"], g["h"], g["w"]
+    noise, c, uc = weights.synth_inputs(1, T, h, w, O.KUBRIC.context_dim,
+                                        O.KUBRIC.adm_in_channels + O.KUBRIC.aux_emb_dim, g["input_seed"])
+    st = g["steps"][1]                      # the mid-schedule one (sigma 3 -> 2): x and D weigh alike
+    sig, nxt = st["sigma"], st["next_sigma"]
+    x = noise * (1.0 + sig ** 2) ** 0.5
+    with torch.no_grad():
+        got = O.sampler_step(sd, O.KUBRIC, x, sig, nxt, c, uc, T, torch.zeros(2, T), O.guider_scale(T))
+    e = rel_l2(got, st["x_next"])
+    assert float(st["x_next"].std()) > 0.5 and e < 2e-5, f"oracle vs reference at 14x32x32: {e:.2e}"

@@ -84,8 +84,8 @@ def test_product_decoder_has_no_cpu_path_and_rejects_other_modes():
         dec(torch.zeros(3, 4, 8, 8), timesteps=3)
     with pytest.raises(_lib.GcdError, match="no CPU"):
         decode_first_stage(dec, torch.zeros(3, 4, 8, 8))
-    with pytest.raises(TypeError):
-        dec(torch.zeros(3, 4, 8, 8))
+    with pytest.raises(_lib.GcdError, match="no CPU"):     # timesteps defaults to the chunk length
+        dec(torch.zeros(3, 4, 8, 8))                       # (config-only drop-in, diffusion.py:242-245)
     with pytest.raises(NotImplementedError):
         VideoDecoder(**dict(kw, time_mode="all"))
     with pytest.raises(AssertionError):

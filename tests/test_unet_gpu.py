@@ -198,8 +198,14 @@ def test_sampler_vs_reference_golden(gpu, tiny):
     def closure(inp, sigma, cc):           # what DiffusionEngine.sample_video builds
         return den(model, inp, sigma, cc, **extra)
 
-    out_generic = sampler(closure, noise.clone().to(gpu), cond=cg, uc=ucg)
+    class Opaque:                          # a callable the sampler cannot see into: generic path
+        def __call__(self, inp, sigma, cc):
+            return den(model, inp, sigma, cc, **extra)
+
+    out_generic = sampler(Opaque(), noise.clone().to(gpu), cond=cg, uc=ucg)
     assert sampler.last_path == "generic"
+    out_closure = sampler(closure, noise.clone().to(gpu), cond=cg, uc=ucg)
+    assert sampler.last_path == "fused", "the sample_video-style closure must reach the fused loop"
     sampler.use_graph = False
     out_fused = sampler(fused, noise.clone().to(gpu), cond=cg, uc=ucg)
     assert sampler.last_path == "fused"
@@ -213,6 +219,7 @@ def test_sampler_vs_reference_golden(gpu, tiny):
         print(f"sampler {name}: rel-L2 vs reference golden {e:.3e}")
         assert e < 1.5 * TOL_LOOP, f"{name}: {e:.3e}"
     assert torch.equal(out_fused, out_graph), "hipGraph replay differs from eager launches"
+    assert torch.equal(out_closure, out_graph), "closure-recovered fused path differs from FusedDenoiser"
     # the two paths differ by ~1 ulp in c_in / c_noise; fp16 operand quantisation decorrelates the
     # rounding noise within a few layers, so they agree to the noise level, not to the ulp
     assert rel_l2(out_fused, out_generic) < 1.5 * TOL_LOOP
@@ -272,3 +279,159 @@ def test_sampler_25_steps_full_width_vs_oracle(gpu):
     e = rel_l2(out, ref)
     print(f"full-width 25-step loop rel-L2 {e:.3e}")
     assert sampler.last_path == "fused" and e < TOL_LOOP, f"full-width 25-step loop: rel-L2 {e:.3e}"
+
+
+# ------------------------------------------------------------------------------------------------
+# the metric's own shapes (BASELINE.json cfg0 / cfg1 / cfg3) against goldens made by the reference
+# modules in the build container (oracle/make_golden_fullres.py, oracle/make_golden_cfg3.py)
+# ------------------------------------------------------------------------------------------------
+def _sample64(t, n=4096):
+    f = t.reshape(-1)
+    idx = torch.linspace(0, f.numel() - 1, min(n, f.numel()), dtype=torch.float64).long()
+    return f[idx.to(f.device)].cpu()
+
+
+@pytest.fixture(scope="module")
+def kubric_full(gpu):
+    net, sd = _build(O.KUBRIC, gpu, salt=2)
+    yield net
+    del net
+    torch.cuda.empty_cache()
+
+
+def test_unet_forward_72x128_full_width_vs_reference_golden(gpu, kubric_full):
+    """cfg1's shape: the 1.53 B-parameter Kubric VideoUNet on N = 28 frames of 72 x 128 latents
+    (S = 9216 attention, 1008-tile persistent GEMMs, the 4.5 GiB slab pool) against strided samples
+    of the reference modules' own forward (185 s on the CPU), output and every block."""
+    net = kubric_full
+    g = torch.load(GOLD / "unet_kubric_72x128.pt")
+    T, h, w = g["T"], g["h"], g["w"]
+    x, ts, ctx, y, ioi = _unet_inputs(O.KUBRIC, T, h, w, g["input_seed"])
+    net.engine.taps = {}
+    out = net(x.to(gpu), ts.to(gpu), context=ctx.to(gpu), y=y.to(gpu), num_video_frames=T,
+              image_only_indicator=ioi.to(gpu))
+    torch.cuda.synchronize()
+    taps, net.engine.taps = net.engine.taps, None
+    assert tuple(out.shape) == tuple(g["out_shape"]) and set(taps) == set(g["tap_samples"])
+    errs = {}
+    for k, v in taps.items():
+        assert tuple(v.shape) == tuple(g["tap_shapes"][k]), k
+        errs[k] = rel_l2(_sample64(v), g["tap_samples"][k])
+        nrm = float(v.double().norm())
+        assert abs(nrm / g["tap_norms"][k] - 1.0) < 2e-3, f"{k}: norm {nrm} vs {g['tap_norms'][k]}"
+    taps.clear()
+    worst = max(errs, key=errs.get)
+    print("72x128 per-block rel-L2:", {k: f"{e:.2e}" for k, e in errs.items()})
+    assert errs[worst] < TOL_FWD, f"block {worst}: rel-L2 {errs[worst]:.3e}"
+    e = rel_l2(_sample64(out, 65536), g["out_samples"])
+    nrm = float(out.double().norm())
+    print(f"72x128 full-width forward: rel-L2 {e:.3e} on 65536 samples, norm {nrm:.4f} vs {g['out_norm']:.4f}")
+    assert e < TOL_FWD, f"UNet forward at 28x72x128 vs reference golden: rel-L2 {e:.3e}"
+    assert abs(nrm / g["out_norm"] - 1.0) < 2e-3
+
+
+def test_sampler_step_32x32_cfg0_vs_reference_golden(gpu, kubric_full):
+    """BASELINE.json cfg0: one EulerEDM sampler_step of the full-width network on a 14 x 32 x 32 x 4
+    latent, at the first step's noise level and a mid-schedule one, generic and fused paths, against
+    the reference plugin stack's own result."""
+    net = kubric_full
+    g = torch.load(GOLD / "step_kubric_32x32.pt")
+    T, h, w = g["T"], g["h"], g["w"]
+    noise, c, uc = weights.synth_inputs(1, T, h, w, O.KUBRIC.context_dim,
+                                        O.KUBRIC.adm_in_channels + O.KUBRIC.aux_emb_dim, g["input_seed"])
+    cg = {k: v.to(gpu) for k, v in c.items()}
+    ucg = {k: v.to(gpu) for k, v in uc.items()}
+    den, model, extra, fused = _stack(net, T, gpu)
+    sampler = _sampler(T, 25, "cuda")
+    from gcd_amd.sampling import FusedEulerLoop
+    for st in g["steps"]:
+        sig, nxt = st["sigma"], st["next_sigma"]
+        x = (noise * (1.0 + sig ** 2) ** 0.5).to(gpu)
+        s_in = x.new_ones([x.shape[0]])
+        out_gen = sampler.sampler_step(s_in * sig, s_in * nxt, fused, x, cg, ucg)
+        loop = FusedEulerLoop(sampler, fused, noise.clone().to(gpu), cg, ucg)
+        with loop:
+            loop.x.copy_(x)
+            loop.sig.copy_(torch.tensor([sig, nxt], device=gpu))
+            loop.launch_step()
+        loop.close()
+        # x_next = x + (s'/s - 1) (x - D): remove the part carried by x itself so the figure measures D
+        carried = (x * (nxt / sig)).cpu()
+        ref_d = st["x_next"] - carried
+        for name, o in (("generic", out_gen), ("fused", loop.x)):
+            e_x = rel_l2(o, st["x_next"])
+            e_d = rel_l2(o.cpu() - carried, ref_d)
+            print(f"cfg0 step sigma {sig}->{nxt} [{name}]: rel-L2 x_next {e_x:.3e}, denoised part {e_d:.3e}")
+            assert e_x < TOL_LOOP, f"{name} sigma {sig}: x_next rel-L2 {e_x:.3e}"
+            # D = CFG mix of two forwards (x_u + s (x_c - x_u), s up to 1.5): ~1.3-1.6x one forward's error
+            assert e_d < 2 * TOL_FWD, f"{name} sigma {sig}: denoised-part rel-L2 {e_d:.3e}"
+
+
+def test_sampler_50_steps_pardom_cfg3_vs_reference_golden(gpu):
+    """BASELINE.json cfg3: the ParDom network (no aux_label_emb, y 768 wide), the full 50-step
+    EulerEDM loop with CFG on 14 frames, against the reference plugin stack's own trajectory."""
+    g = torch.load(GOLD / "sampler_pardom_50.pt")
+    net, sd = _build(O.PARDOM, gpu, salt=g["salt"])
+    T, steps, h, w = g["T"], g["steps"], g["h"], g["w"]
+    noise, c, uc = weights.synth_inputs(1, T, h, w, O.PARDOM.context_dim,
+                                        O.PARDOM.adm_in_channels + O.PARDOM.aux_emb_dim, g["input_seed"])
+    den, model, extra, fused = _stack(net, T, gpu)
+    sampler = _sampler(T, steps, "cuda")
+    from gcd_amd.sampling import FusedEulerLoop
+    loop = FusedEulerLoop(sampler, fused, noise.clone().to(gpu),
+                          {k: v.to(gpu) for k, v in c.items()}, {k: v.to(gpu) for k, v in uc.items()})
+    assert loop.num_steps == 50
+    errs = {}
+    with loop:
+        for i in range(loop.num_steps):
+            loop.step(i)
+            if i + 1 in g["trace"]:
+                loop.side.synchronize()
+                errs[i + 1] = rel_l2(loop.x, g["trace"][i + 1])
+    loop.close()
+    e = rel_l2(loop.x, g["final"])
+    print("cfg3 trajectory rel-L2:", {k: f"{v:.2e}" for k, v in errs.items()}, f"final {e:.3e}")
+    assert max(errs.values()) < TOL_LOOP and e < TOL_LOOP, f"50-step ParDom loop: rel-L2 {e:.3e}"
+    del net
+    torch.cuda.empty_cache()
+
+
+def test_two_clips_batched_with_image_only_indicator(gpu, tiny):
+    """num_samples / batched clips: B = 2 clips in one call (56 frames under CFG: per-clip time_stack
+    GroupNorm, per-clip first-frame temporal context, > 32 rows through the small-M kernel), with a
+    non-zero image_only_indicator (4, 14) — UNet forward and the fused 5-step loop vs the oracle."""
+    net, sd = tiny
+    T, h, w, B = 14, 8, 8, 2
+    cfg = O.TINY
+    noise, c, uc = weights.synth_inputs(B, T, h, w, cfg.context_dim, cfg.adm_in_channels + cfg.aux_emb_dim, 77)
+    ioi = torch.zeros(2 * B, T)
+    ioi[0, 3] = ioi[1, 0] = ioi[2, 13] = ioi[3, 5] = ioi[3, 6] = 1.0
+    x = torch.cat([torch.cat([noise, uc["concat"]], 1), torch.cat([noise, c["concat"]], 1)])
+    ts = torch.linspace(-1.2, 1.4, 2 * B * T)
+    ctx = torch.cat([uc["crossattn"], c["crossattn"]])
+    y = torch.cat([uc["vector"], c["vector"]])
+    with torch.no_grad():
+        ref = O.unet_forward(sd, cfg, x, ts, ctx, y, T, ioi)
+    out = net(x.to(gpu), ts.to(gpu), context=ctx.to(gpu), y=y.to(gpu), num_video_frames=T,
+              image_only_indicator=ioi.to(gpu))
+    e = rel_l2(out, ref)
+    assert out.shape[0] == 56 and e < TOL_FWD, f"B=2 forward: rel-L2 {e:.3e}"
+    # clips are independent: clip 1 of the batch == the same clip run alone (same ioi rows)
+    sel = torch.cat([torch.arange(T, 2 * T), torch.arange(3 * T, 4 * T)])
+    alone = net(x[sel].to(gpu), ts[sel].to(gpu), context=ctx[sel].to(gpu), y=y[sel].to(gpu),
+                num_video_frames=T, image_only_indicator=ioi[[1, 3]].to(gpu))
+    assert rel_l2(out[sel.to(gpu)], alone) < 2e-4
+    steps = 5
+    with torch.no_grad():
+        ref_loop = O.sample_loop(sd, cfg, noise, c, uc, T, steps, ioi2=ioi)
+    from gcd_amd.denoiser import Denoiser
+    from gcd_amd.sampling import FusedDenoiser
+    from gcd_amd.wrappers import OpenAIWrapper
+    fd = FusedDenoiser(Denoiser({"target": "gcd_amd.denoiser_scaling.VScalingWithEDMcNoise"}),
+                       OpenAIWrapper(net), num_video_frames=T, image_only_indicator=ioi.to(gpu))
+    sampler = _sampler(T, steps, "cuda")
+    got = sampler(fd, noise.clone().to(gpu), cond={k: v.to(gpu) for k, v in c.items()},
+                  uc={k: v.to(gpu) for k, v in uc.items()})
+    e = rel_l2(got, ref_loop)
+    print(f"B=2 fused loop rel-L2 {e:.3e}")
+    assert sampler.last_path == "fused" and got.shape[0] == B * T and e < 1.5 * TOL_LOOP

@@ -7,6 +7,9 @@
 //   hipcc -O2 --offload-arch=gfx950 tools/gemm_bench.cpp -Iinclude -Lgcd_amd -lgcd_amd \
 //         -Wl,-rpath,'$ORIGIN/../gcd_amd' -o tools/gemm_bench
 //   tools/gemm_bench [quick|full] [iters]
+// The ablation variants (impl >= 32) exist only in tools/libgcd_amd_ablate.so
+// (`python -m gcd_amd.csrc.build --ablation`, then link with -Ltools -lgcd_amd_ablate instead); against
+// the product library those impl numbers fall through to the product kernel.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>

@@ -53,6 +53,7 @@ def main():
     ap.add_argument("fetch_csv")
     ap.add_argument("write_csv")
     ap.add_argument("--json", default="")
+    ap.add_argument("--source", default="", help="name of the profile this JSON was made from (recorded)")
     a = ap.parse_args()
     f_tot, f_cnt = load(a.fetch_csv)
     w_tot, w_cnt = load(a.write_csv)
@@ -70,6 +71,13 @@ def main():
         out[fam] = dict(launches=n, fetch_mb_raw=round(fetch_mb, 1), fetch_mb_x2=round(2 * fetch_mb, 1),
                         write_mb=round(write_mb, 1), bytes_per_launch=round(per * 1e6))
     if a.json:
+        # stamp with the digest of the sources the counters were collected on (bench.py refuses to
+        # quote a profile whose digest differs from the build it runs)
+        import pathlib
+        sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+        from gcd_amd.csrc import build as _b
+        out["sources_digest"] = _b.sources_digest()
+        out["source"] = a.source or a.json
         with open(a.json, "w") as f:
             json.dump(out, f, indent=1)
 
