@@ -11,7 +11,7 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libgcd_amd.so"
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # GEMM modes / output kinds (mirror include/gcd_amd.h)
 GEMM_PLAIN, GEMM_CONV3X3, GEMM_TEMPORAL3 = 0, 1, 2
@@ -41,6 +41,7 @@ class GemmDesc(C.Structure):
         ("ln_addvec", C.c_void_p), ("ld_ln_addvec", C.c_int64), ("ln_sum_out", C.c_void_p),
         ("ld_ln_sum", C.c_int64),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("asym_pad", C.c_int32),
+        ("colstats", C.c_void_p),
     ]
 
 
@@ -54,6 +55,8 @@ SIGNATURES = {
     "gcd_tune_set": (_i, [_i, _i]),
     "gcd_gemm_f16": (_i, [C.POINTER(GemmDesc), _vp]),
     "gcd_gemm_ln_fusable": (_i, [_i, _i, _i, _i]),
+    "gcd_gemm_colstats_supported": (_i, [C.POINTER(GemmDesc)]),
+    "gcd_groupnorm_stats_from_colsums": (_i, [_vp, _i, _vp, _i, _i64, _i64, _f, _vp, _vp]),
     "gcd_linear_smallm_f32": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "gcd_groupnorm_stats": (_i, [_vp, _i64, _i, _vp, _i64, _i, _i64, _i64, _f, _vp, _i, _vp, _vp]),
     "gcd_groupnorm_apply": (_i, [_vp, _i64, _i, _vp, _i64, _i, _i64, _i64, _vp, _vp, _vp, _i, _vp,

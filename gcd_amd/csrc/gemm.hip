@@ -302,6 +302,17 @@ static int dispatch_tile(const GemmK& k, hipStream_t s) {
   return launch_gemm<128, 128, 64, 64, MODE>(k, s);
 }
 
+// Conditions under which EVERY tile of the launch takes the row-major fp32 fast epilogue of the
+// ping-pong kernel, the only one that produces column statistics: full 256 x 320 tiles, fp32 output,
+// at most one residual, no fused LayerNorm, per-frame vectors / blend factors constant over a tile.
+static bool colstats_shape_ok(const gcd_gemm_desc* d) {
+  if (d->out_kind != GCD_OUT_F32 || d->R2 || d->ln_out16) return false;
+  if (d->M % 256 != 0 || d->N % 320 != 0) return false;
+  if (d->rowvec && d->rows_per_vec % 256 != 0) return false;
+  if (d->frame_alpha && d->rows_per_alpha % 256 != 0) return false;
+  return true;
+}
+
 // Implicit-GEMM geometry of a descriptor (conv3x3: pad 1 / stride 1-2 / fused x2 upsample /
 // asymmetric pad; temporal3: clips of T frames x HW tokens).  0 = fine, else the error is set.
 static int validate_geometry(const gcd_gemm_desc* d) {
@@ -416,6 +427,7 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
   k.ld_ln_sum = d->ld_ln_sum;
   k.splitk = 1;
   k.split_stride = 0;
+  k.colstats = d->colstats;
   hipStream_t s = (hipStream_t)stream;
 
   // kernel choice: the 256 x 320 ping-pong kernel whenever the grid fills most of the chip with
@@ -443,12 +455,17 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
                 "gcd_gemm_f16: K=%d (Cin=%d) needs the ping-pong kernel, which the shape or "
                 "GCD_TUNE_GEMM_IMPL=%d rules out", d->K, d->Cin, impl);
 
+  if (d->colstats)
+    GCD_CHECK_ARG(use_pp && colstats_shape_ok(d) && ((uintptr_t)d->colstats & 15) == 0,
+                  "gcd_gemm_f16: colstats cannot be honoured for this descriptor (M=%d N=%d; see "
+                  "gcd_gemm_colstats_supported)", d->M, d->N);
+
   // mode-specific geometry, checked BEFORE any kernel choice (split-K included): a malformed conv /
   // temporal descriptor must come back as an argument error, never reach a gather
   if (const int rc = validate_geometry(d)) return rc;
 
   // split-K: few 256x320 tiles (<= 96 of 256 CUs) and a long K — the 3x3 convs of the 9x16 level
-  if (d->workspace && !d->ln_out16 && d->out_kind != GCD_OUT_GEGLU && (impl == 0 || impl == 7) &&
+  if (d->workspace && !d->ln_out16 && !d->colstats && d->out_kind != GCD_OUT_GEGLU && (impl == 0 || impl == 7) &&
       gcd_gemm_pp_supported(k, d->mode) && d->N >= 160 && d->N % 4 == 0) {
     const int64_t tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 319) / 320);
     int splitk = (int)(256 / tiles);
@@ -470,6 +487,16 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
       if (use_pp) return gcd_gemm_pp_launch(k, d->mode, s);
       return dispatch_tile<GCD_GEMM_TEMPORAL3>(k, s);
   }
+}
+
+extern "C" int gcd_gemm_colstats_supported(const gcd_gemm_desc* d) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->K % 32 != 0 || !colstats_shape_ok(d)) return 0;
+  if (d->mode != GCD_GEMM_PLAIN && (d->Cin <= 0 || d->Cin % 32 != 0)) return 0;
+  const int impl = gcd_tune_get(GCD_TUNE_GEMM_IMPL);
+  if (impl == 1 || impl == 5 || impl == 6) return 0;          // general kernel forced
+  const int64_t tiles = (int64_t)(d->M / 256) * (d->N / 320);
+  if ((impl == 0 || impl == 7) && tiles < 192) return 0;      // automatic choice: general kernel / split-K
+  return 1;
 }
 
 extern "C" int gcd_gemm_ln_fusable(int M, int N, int K, int mode) {

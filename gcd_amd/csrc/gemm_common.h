@@ -41,6 +41,9 @@ struct GemmK {
   // fp32 partial sums at out + slice * split_stride (elements)
   int splitk;
   int64_t split_stride;
+  // per-64-row column sums / sums of squares of the fp32 output for the next GroupNorm
+  // (gcd_gemm_desc.colstats): [2 * M / 64, N]
+  float* colstats;
 };
 
 // gemm_pp.hip: the 256 x 320 ping-pong kernel.
@@ -191,7 +194,30 @@ __device__ __forceinline__ void gcd_epilogue_64x160_ln(const GemmK& p, f32x16 (&
 // wave-private LDS tile (`stage`, >= 4608 B): lane -> row 8 qq + (lane >> 3), channels 4 (lane & 7),
 // and the residual vectors are fetched in that layout, D tiles ahead.  sa / sr1 / sr2 are
 // wave-uniform here (the caller checked that one frame_alpha entry serves the whole tile).
-template <bool HAS_R1, bool HAS_R2, bool OUT16 = false>
+// Sum over the 8 lanes that differ in lane bits 3, 4, 5 (same lane & 7), result in all of them — three
+// VALU cross-lane ops (DPP row rotate by 8, v_permlane16_swap, v_permlane32_swap), no LDS round trip:
+// eight dependent ds_bpermute chains per column block made the statistics cost ~3 % of a conv launch.
+__device__ __forceinline__ float gcd_sum_lane_bits_345(float a) {
+  const int v = __float_as_int(a);
+  a += __int_as_float(__builtin_amdgcn_update_dpp(v, v, 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+  {
+    const unsigned u = __float_as_uint(a);
+    const auto sw = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    a = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+  {
+    const unsigned u = __float_as_uint(a);
+    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    a = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+  return a;
+}
+
+// STATS: also reduce the stored values per column over the wave's 64 rows (sum, sum of squares) and
+// write them to p.colstats — a lane owns 4 fixed channels of every 32-column block and 8 of its rows
+// (rr + 8 qq + 32 j), so one block costs 8 adds + 8 FMAs per lane on values it holds anyway, then an
+// 8-lane tree over the lanes that share those channels (lane bits 3-5).
+template <bool HAS_R1, bool HAS_R2, bool OUT16 = false, bool STATS = false>
 __device__ __forceinline__ void gcd_epi_f32_rows_full(const GemmK& p, f32x16 (&acc)[5][2], int m_base,
                                                      int n_base, int lane, const float* lb, char* stage,
                                                      float sa, float sr1, float sr2) {
@@ -220,6 +246,7 @@ __device__ __forceinline__ void gcd_epi_f32_rows_full(const GemmK& p, f32x16 (&a
 #pragma unroll
     for (int b = 0; b < D; ++b) fetch(b, b);
   }
+  f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int b = 0; b < 10; ++b) {
     const int i = b >> 1, j = b & 1;
@@ -237,6 +264,11 @@ __device__ __forceinline__ void gcd_epi_f32_rows_full(const GemmK& p, f32x16 (&a
       v = (v + bv) * sa;
       if (HAS_R1) v += sr1 * q1[b % D][qq];
       if (HAS_R2) v += sr2 * q2[b % D][qq];
+      if (STATS) {
+        cs += v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cq[e] = fmaf(v[e], v[e], cq[e]);
+      }
       if (OUT16) {
         f16x4 o;
 #pragma unroll
@@ -247,6 +279,22 @@ __device__ __forceinline__ void gcd_epi_f32_rows_full(const GemmK& p, f32x16 (&a
       }
     }
     if ((HAS_R1 || HAS_R2) && b + D < 10) fetch(b + D, b % D);
+    if (STATS && j == 1) {
+      // both token halves of column block i are in: fold the 8 lanes (rr = 0..7) that hold the same
+      // 4 channels, lanes 0-7 write [sum | sumsq] of the wave's 64 rows
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        cs[e] = gcd_sum_lane_bits_345(cs[e]);
+        cq[e] = gcd_sum_lane_bits_345(cq[e]);
+      }
+      if (rr == 0) {
+        float* dst = p.colstats + (int64_t)(m_base >> 6) * 2 * p.N + col + 32 * i;
+        *(f32x4*)dst = cs;
+        *(f32x4*)(dst + p.N) = cq;
+      }
+      cs = f32x4{0.f, 0.f, 0.f, 0.f};
+      cq = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     __builtin_amdgcn_sched_barrier(0);   // keep the pipeline order (and the register budget) as written
   }
 }

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
     }
     // epilogue addends of this tile's 320 columns: bias, plus the rowvec row when one row serves
     // the whole tile (always at the 72x128 / 36x64 levels: 9216 and 2304 rows per frame)
-    if (!(VAR & (16384 | 8192))) {
+    if (!(VAR & (16384 | 8192))) {   // (the colstats build, VAR & 4096, stages them too)
       const int m_last = min(m0 + PP_BM, p.M) - 1;
       const bool rv_uni = !p.rowvec || (m0 / p.rows_per_vec == m_last / p.rows_per_vec);
       lds_bias_ok = rv_uni;
@@ -368,6 +368,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
     gcd_epilogue_64x160<8>(q, acc, wm_base, wn_base, elane, smem);
   } else if constexpr ((VAR & 8192) != 0) {   // own instantiation: fused LayerNorm (N == 320)
     gcd_epilogue_64x160_ln(p, acc, wm_base, wn_base, elane, wm, wn, (float*)smem);
+  } else if constexpr ((VAR & 4096) != 0) {
+    // own instantiation: fp32 rows + per-64-row column statistics for the next GroupNorm
+    // (gcd_gemm_desc.colstats).  gcd_gemm_f16 validated that EVERY tile of the launch is full, has
+    // tile-uniform per-frame vectors / blend factors and at most one residual.
+    float sa = p.s_acc, sr1 = p.s_r1;
+    if (p.frame_alpha) {
+      const float al = p.frame_alpha[m0 / p.rows_per_alpha];
+      sa = 1.0f - al;
+      if (p.r1_blend) sr1 *= 1.0f - al;
+    }
+    const float* lb = lds_bias + 160 * wn;
+    char* stage = smem + wave * GCD_EPI_STAGE_BYTES;
+    p.R1 ? gcd_epi_f32_rows_full<true, false, false, true>(p, acc, wm_base, wn_base, elane, lb, stage, sa, sr1, 0.f)
+         : gcd_epi_f32_rows_full<false, false, false, true>(p, acc, wm_base, wn_base, elane, lb, stage, sa, sr1, 0.f);
   } else {
     constexpr int EV = ((VAR >> 6) & 31) | ((VAR & 32768) ? 32 : 0);
     const bool full = wm_base + 64 <= p.M && wn_base + 160 <= p.N && lds_bias_ok;
@@ -559,6 +573,17 @@ int gcd_gemm_pp_launch(const GemmK& k, int mode, hipStream_t s) {
       return 2;
     }
     return persist ? launch_pp<GCD_GEMM_PLAIN, 2048 + 8192>(k, s) : launch_pp<GCD_GEMM_PLAIN, 8192>(k, s);
+  }
+  if (k.colstats) {   // validated by gcd_gemm_f16 (colstats_shape_ok)
+    switch (mode) {
+      case GCD_GEMM_PLAIN:
+        return persist ? launch_pp<GCD_GEMM_PLAIN, 2048 + 4096>(k, s) : launch_pp<GCD_GEMM_PLAIN, 4096>(k, s);
+      case GCD_GEMM_CONV3X3:
+        return persist ? launch_pp<GCD_GEMM_CONV3X3, 2048 + 4096>(k, s) : launch_pp<GCD_GEMM_CONV3X3, 4096>(k, s);
+      default:
+        return persist ? launch_pp<GCD_GEMM_TEMPORAL3, 2048 + 4096>(k, s)
+                       : launch_pp<GCD_GEMM_TEMPORAL3, 4096>(k, s);
+    }
   }
   switch (mode) {
     case GCD_GEMM_PLAIN:

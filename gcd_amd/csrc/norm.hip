@@ -147,6 +147,83 @@ extern "C" int gcd_groupnorm_stats(const float* x1, int64_t ld1, int C1, const f
 }
 
 // ------------------------------------------------------------------------------------------------
+// GroupNorm statistics from the column sums a producing GEMM epilogue left behind (gemm_common.h,
+// STATS): cs[(2 b + s) * C + c] = sum over the 64 rows of block b of x[., c]^(s + 1).  No pass over x.
+// grid = (32 groups, ninst), block 256 / 1024: a block folds its group's cg channels over the instance's
+// rows_per_inst / 64 blocks in fp64 (virtual concat: channels >= C1 come from cs2).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void gn_stats_colsums_kernel(const float* __restrict__ cs1, int C1,
+                                                               const float* __restrict__ cs2, int C2,
+                                                               int blocks_per_inst, double count,
+                                                               float eps, float* __restrict__ stats) {
+  __shared__ double red[2][16];
+  const int g = blockIdx.x, inst = blockIdx.y, t = threadIdx.x;
+  const int nthr = blockDim.x, nwave = nthr >> 6;
+  const int cg = (C1 + C2) / 32;
+  const int64_t b0 = (int64_t)inst * blocks_per_inst;
+  const int total = blocks_per_inst * cg;
+  double s = 0.0, q = 0.0;
+  for (int idx = t; idx < total; idx += nthr) {
+    const int b = idx / cg;
+    const int c = g * cg + (idx - b * cg);
+    const float* src;
+    int ld;
+    if (c < C1) {
+      src = cs1 + c;
+      ld = C1;
+    } else {
+      src = cs2 + (c - C1);
+      ld = C2;
+    }
+    const int64_t row = (b0 + b) * 2;
+    s += (double)src[row * ld];
+    q += (double)src[(row + 1) * ld];
+  }
+  s = wave_sum_d(s);
+  q = wave_sum_d(q);
+  if ((t & 63) == 0) {
+    red[0][t >> 6] = s;
+    red[1][t >> 6] = q;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double sum = 0.0, sq = 0.0;
+    for (int w = 0; w < nwave; ++w) {
+      sum += red[0][w];
+      sq += red[1][w];
+    }
+    const double mean = sum / count;
+    double var = sq / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[inst * 64 + 2 * g] = (float)mean;
+    stats[inst * 64 + 2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+extern "C" int gcd_groupnorm_stats_from_colsums(const float* cs1, int C1, const float* cs2, int C2,
+                                                int64_t M, int64_t rows_per_inst, float eps,
+                                                float* stats, void* stream) {
+  const int C = C1 + C2;
+  GCD_CHECK_ARG(cs1 && stats, "gcd_groupnorm_stats_from_colsums: null pointer");
+  GCD_CHECK_ARG(C1 > 0 && C2 >= 0 && C % 32 == 0 && (C2 == 0 || cs2),
+                "gcd_groupnorm_stats_from_colsums: channels C1=%d C2=%d", C1, C2);
+  GCD_CHECK_ARG(rows_per_inst > 0 && rows_per_inst % 64 == 0 && M > 0 && M % rows_per_inst == 0,
+                "gcd_groupnorm_stats_from_colsums: M=%lld rows_per_inst=%lld (need 64-row blocks that "
+                "do not straddle instances)", (long long)M, (long long)rows_per_inst);
+  const int64_t bpi = rows_per_inst / 64;
+  GCD_CHECK_ARG(bpi * (C / 32) < (1ll << 31), "gcd_groupnorm_stats_from_colsums: instance too large");
+  const int ninst = (int)(M / rows_per_inst);
+  const double count = (double)rows_per_inst * (double)(C / 32);
+  // few instances with many blocks each (the time_stack GroupNorm: 2 clips x 2016 blocks at 72x128):
+  // 1024 threads per (group, instance) keep the per-thread chains short
+  const int nthr = bpi * (C / 32) > 4096 ? 1024 : 256;
+  hipLaunchKernelGGL(gn_stats_colsums_kernel, dim3(32, ninst), dim3(nthr), 0, (hipStream_t)stream, cs1,
+                     C1, cs2, C2, (int)bpi, count, eps, stats);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // GroupNorm apply (+SiLU) -> fp16, optional raw fp16 copy.
 // grid = (row chunks, ninst); block 256.  Per-channel scale/shift are built once per block in LDS.
 // ------------------------------------------------------------------------------------------------
@@ -160,7 +237,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
   const int C = C1 + C2;
   float* sh = sc + C;            // [C] shift
   const int cg = C / 32;
-  const int inst = blockIdx.y;
+  const bool rev = (silu & 2) != 0;     // walk the tensor from its end (see gcd_amd.h)
+  silu &= 1;
+  const int inst = rev ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+  const int chunk = rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
   const int t = threadIdx.x;
   for (int c = t; c < C; c += 256) {
     const int g = c / cg;
@@ -174,7 +254,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
   // store 512 B — whole 128-byte lines per instruction (8 channels per lane left every load
   // instruction with half-used lines).  Two vectors in flight per thread.
   const int cv4 = C >> 2;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk;
+  const int64_t r0 = (int64_t)chunk * rows_per_chunk;
   int64_t nrows = rows_per_inst - r0;
   if (nrows > rows_per_chunk) nrows = rows_per_chunk;
   const int64_t base = (int64_t)inst * rows_per_inst + r0;

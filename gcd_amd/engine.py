@@ -32,6 +32,7 @@ CIN_PAD = 64    # first conv: input channels padded to the GEMM K granule
 COUT_PAD = 16   # last conv: output channels padded to the GEMM N granule
 
 
+_GN_REVERSE = os.environ.get("GCD_GN_REVERSE", "1") != "0"   # A/B switch (see ops.groupnorm_apply)
 _ITEMSIZE = {torch.float16: 2, torch.float32: 4, torch.float64: 8, torch.uint8: 1}
 
 
@@ -52,11 +53,25 @@ class Workspace:
         self._complete = False
         self._replay = False
         self._k = 0
+        self._aux: Dict[int, torch.Tensor] = {}   # data_ptr of a buffer -> side buffer that lives with it
+
+    def attach(self, t: torch.Tensor, aux: Optional[torch.Tensor]) -> None:
+        """Tie a side buffer (the GroupNorm column sums of `t`) to `t`: released with it, replaced
+        (and the old one released) when `t` is rewritten."""
+        old = self._aux.pop(t.data_ptr(), None)
+        if old is not None:
+            self.free[self.by_ptr[old.data_ptr()]] = True
+        if aux is not None:
+            self._aux[t.data_ptr()] = aux
+
+    def attached(self, t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        return None if t is None else self._aux.get(t.data_ptr())
 
     def reset(self, signature=None) -> None:
         for i in range(len(self.free)):
             self.free[i] = True
         self._k = 0
+        self._aux.clear()
         if signature is None or signature != self._sig or not self._complete:
             self._sig, self._trace, self._complete, self._replay = signature, [], False, False
         else:
@@ -95,6 +110,9 @@ class Workspace:
         for t in tensors:
             if t is None:
                 continue
+            aux = self._aux.pop(t.data_ptr(), None)
+            if aux is not None:
+                self.free[self.by_ptr[aux.data_ptr()]] = True
             self.free[self.by_ptr[t.data_ptr()]] = True
 
     def nbytes(self) -> int:
@@ -296,15 +314,40 @@ class UNetEngine:
         M = x1.shape[0]
         C = x1.shape[1] + (0 if x2 is None else x2.shape[1])
         ninst = M // rows
-        nch = ops.gn_nchunks(rows, ninst)
-        partial = ws.alloc((ninst * nch * 64,), torch.float64)
         stats = ws.alloc((ninst * 64,), torch.float32)
-        ops.groupnorm_stats(x1, x2, rows, eps, partial, stats, nch)
+        reverse = False
+        cs1, cs2 = ws.attached(x1), ws.attached(x2)
+        if cs1 is not None and (x2 is None or cs2 is not None) and rows % 64 == 0:
+            # the GEMM epilogues that wrote x1 (and x2) left per-64-row column sums behind: no
+            # statistics pass over the tensor
+            ops.groupnorm_stats_from_colsums(cs1, x1.shape[1], cs2, 0 if x2 is None else x2.shape[1],
+                                             M, rows, eps, stats)
+            partial = None
+            # nothing has read the tensor since the GEMM wrote it front to back: start at its tail
+            reverse = _GN_REVERSE and x2 is None
+        else:
+            nch = ops.gn_nchunks(rows, ninst)
+            partial = ws.alloc((ninst * nch * 64,), torch.float64)
+            ops.groupnorm_stats(x1, x2, rows, eps, partial, stats, nch)
         y = ws.alloc((M, C), torch.float16)
         raw = ws.alloc((M, C), torch.float16) if want_raw else None
-        ops.groupnorm_apply(x1, x2, rows, stats, affine[0], affine[1], silu, y, raw)
+        ops.groupnorm_apply(x1, x2, rows, stats, affine[0], affine[1], silu, y, raw, reverse=reverse)
         ws.release(partial, stats)
         return y, raw
+
+    def _gemm_gn(self, a16, w16, out, **kw):
+        """`ops.gemm` for an fp32 output that a GroupNorm reads next: where the shape allows
+        (gcd_gemm_colstats_supported) the epilogue also writes the per-64-row column sums and they
+        travel with `out` (Workspace.attach); otherwise any stale sums of `out` are dropped."""
+        ws = self.ws
+        if ops.gemm(a16, w16, out, probe_colstats=True, **kw):
+            cs = ws.alloc((2 * (kw["M"] // 64), w16.shape[0]), torch.float32)
+            ops.gemm(a16, w16, out, colstats=cs, **kw)
+            ws.attach(out, cs)
+        else:
+            ops.gemm(a16, w16, out, **kw)
+            ws.attach(out, None)
+        return out
 
     def _ln(self, x, affine, addvec=None, rows_per_vec=1, sum_out=None):
         y = self.ws.alloc(tuple(x.shape), torch.float16)
@@ -340,8 +383,8 @@ class UNetEngine:
         a16, raw16 = self._gn(x1, x2, HW, 1e-5, L["gn1"], True, L["wskip"] is not None)
         h1 = ws.alloc((M, cout), torch.float32)
         off, n = L["emb"]
-        ops.gemm(a16, L["w1"], h1, M=M, mode=GEMM_CONV3X3, bias=L["b1"], rowvec=emb_all[:, off:off + n],
-                 rows_per_vec=HW, conv=conv)
+        self._gemm_gn(a16, L["w1"], h1, M=M, mode=GEMM_CONV3X3, bias=L["b1"],
+                      rowvec=emb_all[:, off:off + n], rows_per_vec=HW, conv=conv)
         ws.release(a16)
         a16, _ = self._gn(h1, None, HW, 1e-5, L["gn2"], True, False)
         xs = ws.alloc((M, cout), torch.float32)
@@ -349,24 +392,24 @@ class UNetEngine:
         if L["wskip"] is not None:
             ops.gemm(raw16, L["wskip"], xs, M=M, bias=L["bskip"])
             ws.release(raw16)
-            ops.gemm(a16, L["w2"], xs, M=M, mode=GEMM_CONV3X3, bias=L["b2"], r1=xs, conv=conv2)
+            self._gemm_gn(a16, L["w2"], xs, M=M, mode=GEMM_CONV3X3, bias=L["b2"], r1=xs, conv=conv2)
         else:
             assert x2 is None
-            ops.gemm(a16, L["w2"], xs, M=M, mode=GEMM_CONV3X3, bias=L["b2"], r1=x1, conv=conv2)
+            self._gemm_gn(a16, L["w2"], xs, M=M, mode=GEMM_CONV3X3, bias=L["b2"], r1=x1, conv=conv2)
         ws.release(a16)
         # --- time_stack ResBlock (dims 3, kernel (3,1,1), GroupNorm over T*H*W) + AlphaBlender ---
         ts = L["ts"]
         tconv = dict(Cin=cout, T=T, HW=HW)
         a16, _ = self._gn(xs, None, T * HW, 1e-5, ts["gn1"], True, False)
         off, n = ts["emb"]
-        ops.gemm(a16, ts["w1"], h1, M=M, mode=GEMM_TEMPORAL3, bias=ts["b1"],
-                 rowvec=emb_all[:, off:off + n], rows_per_vec=HW, conv=tconv)
+        self._gemm_gn(a16, ts["w1"], h1, M=M, mode=GEMM_TEMPORAL3, bias=ts["b1"],
+                      rowvec=emb_all[:, off:off + n], rows_per_vec=HW, conv=tconv)
         ws.release(a16)
         a16, _ = self._gn(h1, None, T * HW, 1e-5, ts["gn2"], True, False)
         ws.release(h1)
         # out = x_s + (1 - alpha) * (conv + b): alpha*x_s + (1-alpha)*(x_s + conv + b), util.py:364-368
-        ops.gemm(a16, ts["w2"], xs, M=M, mode=GEMM_TEMPORAL3, bias=ts["b2"], r1=xs,
-                 frame_alpha=st["alphas"][L["blend"]], rows_per_alpha=HW, r1_blend=False, conv=tconv)
+        self._gemm_gn(a16, ts["w2"], xs, M=M, mode=GEMM_TEMPORAL3, bias=ts["b2"], r1=xs,
+                      frame_alpha=st["alphas"][L["blend"]], rows_per_alpha=HW, r1_blend=False, conv=tconv)
         ws.release(a16)
         return xs
 
@@ -452,7 +495,7 @@ class UNetEngine:
                          frame_alpha=st["alphas"][L["blend"]], rows_per_alpha=HW, r1_blend=True, ln=req)
             ws.release(xm)
         ws.release(xs)
-        ops.gemm(last, L["wout"], x, M=M, bias=L["bout"], r1=x)       # + x_in
+        self._gemm_gn(last, L["wout"], x, M=M, bias=L["bout"], r1=x)   # + x_in; the next block's GroupNorm reads x
         ws.release(last)
         return x
 
@@ -602,9 +645,9 @@ class UNetEngine:
                 k = L["kind"]
                 if k == "conv_in":
                     h = ws.alloc((M, L["cout"]), torch.float32)
-                    ops.gemm(xin, L["w"], h, M=M, mode=GEMM_CONV3X3, bias=L["b"],
-                             conv=dict(Cin=CIN_PAD, Hi=H, Wi=W, Ho=H, Wo=W, stride=1, upsample=0),
-                             alg_flops_scale=u.in_channels / CIN_PAD)
+                    self._gemm_gn(xin, L["w"], h, M=M, mode=GEMM_CONV3X3, bias=L["b"],
+                                  conv=dict(Cin=CIN_PAD, Hi=H, Wi=W, Ho=H, Wo=W, stride=1, upsample=0),
+                                  alg_flops_scale=u.in_channels / CIN_PAD)
                     ws.release(xin)
                 elif k == "res":
                     hn = self._resblock(L, h, None, st)
@@ -669,8 +712,8 @@ class UNetEngine:
         a16 = ws.alloc((N * H * W, L["cin"]), torch.float16)
         ops.cast_f16(h, a16)
         out = ws.alloc((N * Ho * Wo, L["cout"]), torch.float32)
-        ops.gemm(a16, L["w"], out, M=N * Ho * Wo, mode=GEMM_CONV3X3, bias=L["b"],
-                 conv=dict(Cin=L["cin"], Hi=H, Wi=W, Ho=Ho, Wo=Wo, stride=2, upsample=0))
+        self._gemm_gn(a16, L["w"], out, M=N * Ho * Wo, mode=GEMM_CONV3X3, bias=L["b"],
+                      conv=dict(Cin=L["cin"], Hi=H, Wi=W, Ho=Ho, Wo=Wo, stride=2, upsample=0))
         ws.release(a16)
         if not keep_input:
             ws.release(h)
@@ -685,8 +728,8 @@ class UNetEngine:
         ops.cast_f16(h, a16)
         ws.release(h)
         out = ws.alloc((N * Ho * Wo, L["cout"]), torch.float32)
-        ops.gemm(a16, L["w"], out, M=N * Ho * Wo, mode=GEMM_CONV3X3, bias=L["b"],
-                 conv=dict(Cin=L["cin"], Hi=H, Wi=W, Ho=Ho, Wo=Wo, stride=1, upsample=1))
+        self._gemm_gn(a16, L["w"], out, M=N * Ho * Wo, mode=GEMM_CONV3X3, bias=L["b"],
+                      conv=dict(Cin=L["cin"], Hi=H, Wi=W, Ho=Ho, Wo=Wo, stride=1, upsample=1))
         ws.release(a16)
         st["H"], st["W"] = Ho, Wo
         return out

@@ -94,6 +94,7 @@ def zero_page(device) -> torch.Tensor:
 
 _splitk = {}
 _SPLITK_ON = os.environ.get("GCD_SPLITK", "1") != "0"   # A/B switch
+_COLSTATS_ON = os.environ.get("GCD_COLSTATS", "1") != "0"   # A/B switch: GroupNorm statistics from GEMM epilogues
 
 
 def _splitk_ws(device) -> torch.Tensor:
@@ -119,11 +120,14 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mod
          out_kind: int = OUT_F32, bias=None, rowvec=None, rows_per_vec: int = 1, r1=None, r2=None,
          s_acc: float = 1.0, s_r1: float = 1.0, s_r2: float = 1.0, frame_alpha=None,
          rows_per_alpha: int = 1, r1_blend: bool = False, conv=None,
-         alg_flops_scale: float = 1.0, ln=None) -> torch.Tensor:
+         alg_flops_scale: float = 1.0, ln=None, colstats=None, probe_colstats: bool = False):
     """out = epilogue(A @ W^T); see gcd_gemm_desc in include/gcd_amd.h.
 
     conv: dict(Cin, Hi, Wi, Ho, Wo, stride, upsample) for GEMM_CONV3X3 or dict(Cin, T, HW) for
     GEMM_TEMPORAL3.  a16 is the token-major fp16 activation [rows, Cin].
+    colstats: optional fp32 [2 * M / 64, N] that receives the per-64-row column sums / sums of squares
+    of the fp32 output (gcd_gemm_desc.colstats) for `groupnorm_stats_from_colsums`.
+    probe_colstats: do not launch; return whether `colstats` would be honoured for this call.
     """
     _need_gpu(a16, w16, out)
     assert a16.dtype == torch.float16 and w16.dtype == torch.float16
@@ -162,6 +166,13 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mod
             d.ln_rows_per_vec = ln["rows_per_vec"]
             if ln.get("sum_out") is not None:
                 d.ln_sum_out, d.ld_ln_sum = ln["sum_out"].data_ptr(), _ld(ln["sum_out"])
+    if probe_colstats:
+        return bool(_COLSTATS_ON and _lib.load().gcd_gemm_colstats_supported(C.byref(d)))
+    if colstats is not None:
+        _need_gpu(colstats)
+        assert colstats.dtype == torch.float32 and colstats.is_contiguous() and \
+            colstats.numel() >= 2 * (M // 64) * N
+        d.colstats = colstats.data_ptr()
     if _SPLITK_ON:
         sk = _splitk_ws(a16.device)
         d.workspace, d.workspace_bytes = sk.data_ptr(), sk.numel() * 4
@@ -213,14 +224,27 @@ def groupnorm_stats(x1, x2, rows_per_inst: int, eps: float, partial: torch.Tenso
     return stats
 
 
-def groupnorm_apply(x1, x2, rows_per_inst: int, stats, gamma, beta, silu: bool, y16, raw16=None):
+def groupnorm_stats_from_colsums(cs1, C1: int, cs2, C2: int, M: int, rows_per_inst: int, eps: float,
+                                 stats: torch.Tensor):
+    """GroupNorm statistics of x = [x1 | x2] from the column sums the producing GEMMs left behind
+    (`gemm(..., colstats=...)`): no pass over x."""
+    _need_gpu(cs1, cs2, stats)
+    assert stats.dtype == torch.float32 and stats.numel() >= (M // rows_per_inst) * 64
+    check(_lib.load().gcd_groupnorm_stats_from_colsums(cs1.data_ptr(), C1, _p(cs2), C2, M, rows_per_inst,
+                                                       eps, stats.data_ptr(), _stream()),
+          "gcd_groupnorm_stats_from_colsums")
+    return stats
+
+
+def groupnorm_apply(x1, x2, rows_per_inst: int, stats, gamma, beta, silu: bool, y16, raw16=None,
+                    reverse: bool = False):
     _need_gpu(x1, x2, stats, gamma, beta, y16, raw16)
     M, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[1]
     check(_lib.load().gcd_groupnorm_apply(x1.data_ptr(), _ld(x1), C1, _p(x2),
                                           0 if x2 is None else _ld(x2), C2, M, rows_per_inst,
                                           stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                          int(silu), y16.data_ptr(), _ld(y16), _p(raw16),
+                                          int(silu) | (2 if reverse else 0), y16.data_ptr(), _ld(y16), _p(raw16),
                                           0 if raw16 is None else _ld(raw16), _stream()),
           "gcd_groupnorm_apply")
     return y16

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GCD_AMD_ABI_VERSION 3
+#define GCD_AMD_ABI_VERSION 4
 
 /* ---- library ------------------------------------------------------------------------------ */
 int gcd_abi_version(void);
@@ -121,6 +121,16 @@ typedef struct gcd_gemm_desc {
      (F.pad + Conv2d(stride 2, padding 0), diffusionmodules/model.py:76-91): input pixel
      (2y + ky, 2x + kx), ky, kx in 0..2, Ho = Hi / 2; 0 = the symmetric padding 1 of every other conv. */
   int32_t asym_pad;
+  /* optional GroupNorm pre-reduction of the fp32 OUTPUT (ABI v4): per block of 64 consecutive output
+     rows b = m / 64 and per column n,
+         colstats[(2 b + 0) * N + n] = sum  over the block's rows of out[m][n]
+         colstats[(2 b + 1) * N + n] = sum  over the block's rows of out[m][n]^2
+     of the values exactly as stored (after bias / rowvec / residual / blend), accumulated in fp32 by
+     the tile epilogue that holds them in registers anyway — the GroupNorm that reads this tensor next
+     (gcd_groupnorm_stats_from_colsums) then needs no pass over it.  Honoured only where every tile
+     takes the row-major fast epilogue (gcd_gemm_colstats_supported); otherwise gcd_gemm_f16 fails.
+     [2 * M / 64, N] floats.                                                                        */
+  float* colstats;
 } gcd_gemm_desc;
 
 /* Replaces torch.nn.Linear / Conv2d / Conv3d forward on the hot path:
@@ -132,6 +142,10 @@ int gcd_gemm_f16(const gcd_gemm_desc* desc, void* stream);
 /* 1 if gcd_gemm_f16 would accept the descriptor's fused-LayerNorm request for this shape (the
  * automatic kernel choice lands on the 256x320 ping-pong kernel and N == 320), else 0.          */
 int gcd_gemm_ln_fusable(int M, int N, int K, int mode);
+/* 1 if gcd_gemm_f16 would honour desc->colstats for this descriptor (fp32 out, no second residual,
+ * M % 256 == 0, N % 320 == 0, rowvec / frame_alpha constant over each 256-row tile, the automatic
+ * kernel choice lands on the 256x320 ping-pong kernel without split-K), else 0.                  */
+int gcd_gemm_colstats_supported(const gcd_gemm_desc* desc);
 
 /* y[M,N] (fp32) = [y +] act_out( act_in(x[M,K]) @ W[N,K]^T + b ), fp32 weights, any M >= 1 (rows are processed 32 at a time).
  * act flags: bit0 = SiLU on input, bit1 = SiLU on output, bit2 = accumulate into y.
@@ -149,7 +163,16 @@ int gcd_linear_smallm_f32(const float* x, int64_t ldx, const float* W, const flo
 int gcd_groupnorm_stats(const float* x1, int64_t ld1, int C1, const float* x2, int64_t ld2, int C2,
                         int64_t M, int64_t rows_per_inst, float eps, double* partial, int nchunks,
                         float* stats, void* stream);
-/* y16 = [silu]((x - mean) * rstd * gamma + beta) as fp16 [M, C1+C2]; raw16 (optional) = fp16(x). */
+/* The same statistics from the per-64-row column sums a producing gcd_gemm_f16 left behind
+ * (desc->colstats) instead of a pass over the tensor: x = [x1 | x2] virtual concat with column sums
+ * cs1 [2*M/64, C1] and cs2 [2*M/64, C2] (cs2 NULL when C2 == 0); rows_per_inst % 64 == 0.
+ * fp64 accumulation over the blocks.  stats as gcd_groupnorm_stats.                               */
+int gcd_groupnorm_stats_from_colsums(const float* cs1, int C1, const float* cs2, int C2, int64_t M,
+                                     int64_t rows_per_inst, float eps, float* stats, void* stream);
+/* y16 = [silu]((x - mean) * rstd * gamma + beta) as fp16 [M, C1+C2]; raw16 (optional) = fp16(x).
+ * silu: bit 0 = apply SiLU; bit 1 = walk the rows from the END of the tensor (pure scheduling: when
+ * the tensor was just written front to back by a GEMM and not read since, its tail is what the
+ * 256 MB Infinity Cache still holds).                                                              */
 int gcd_groupnorm_apply(const float* x1, int64_t ld1, int C1, const float* x2, int64_t ld2, int C2,
                         int64_t M, int64_t rows_per_inst, const float* stats, const float* gamma,
                         const float* beta, int silu, void* y16, int64_t ldy, void* raw16,

@@ -426,6 +426,110 @@ def test_groupnorm(gpu, frames, HW, C1, C2, per_clip_T):
     assert rel_l2(raw.float(), tok) < TOL_F16
 
 
+def _colsum_ref(out, rows=64):
+    b = out.double().reshape(out.shape[0] // rows, rows, out.shape[1])
+    return torch.stack([b.sum(1), (b * b).sum(1)], 1).reshape(-1, out.shape[1])   # [2 * blocks, N]
+
+
+@pytest.mark.parametrize("case", ["plain_r1_persistent", "plain_small", "conv_rowvec", "temporal_alpha"])
+def test_gemm_column_sums_for_groupnorm(gpu, gemm_impl, case):
+    """gcd_gemm_desc.colstats: per-64-row column sums / sums of squares of the fp32 output written by
+    the epilogue that produces it (ping-pong kernel, full tiles), for the three GEMM modes and the
+    epilogue inputs the UNet's GroupNorm producers use; and the statistics derived from them."""
+    from gcd_amd import ops, packing
+    g = _gen(31)
+    kw, ref = {}, None
+    if case in ("plain_r1_persistent", "plain_small"):
+        M, N, K = (256 * 70, 1280, 128) if case == "plain_r1_persistent" else (256 * 3, 320, 64)
+        a = _h(torch.randn(M, K, generator=g))
+        w = _h(torch.randn(N, K, generator=g) / math.sqrt(K))
+        bias = torch.randn(N, generator=g)
+        r1 = torch.randn(M, N, generator=g) + 0.5
+        ref = a @ w.t() + bias + r1
+        A, Wp = a.half().to(gpu), w.half().to(gpu)
+        kw = dict(M=M, bias=bias.to(gpu), r1=r1.to(gpu))
+    elif case == "conv_rowvec":
+        frames, H, W, Cin, N = 3, 16, 32, 64, 320            # HW = 512: rowvec constant over every tile
+        M = frames * H * W
+        x = _h(torch.randn(frames, Cin, H, W, generator=g))
+        wt = _h(torch.randn(N, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+        bias = torch.randn(N, generator=g)
+        rv = torch.randn(frames, N, generator=g)
+        ref = (F.conv2d(x, wt, bias, padding=1) + rv[:, :, None, None]).permute(0, 2, 3, 1).reshape(M, N)
+        A = x.permute(0, 2, 3, 1).reshape(M, Cin).contiguous().half().to(gpu)
+        Wp = packing.pack_conv3x3(wt.to(gpu))
+        kw = dict(M=M, mode=ops.GEMM_CONV3X3, bias=bias.to(gpu), rowvec=rv.to(gpu), rows_per_vec=H * W,
+                  conv=dict(Cin=Cin, Hi=H, Wi=W, Ho=H, Wo=W, stride=1, upsample=0))
+    else:
+        clips, T, HW, C = 1, 3, 256, 320
+        M = clips * T * HW
+        x = _h(torch.randn(clips, C, T, HW, generator=g))
+        wt = _h(torch.randn(C, C, 3, generator=g) / math.sqrt(3 * C))
+        bias = torch.randn(C, generator=g)
+        r1 = torch.randn(M, C, generator=g)
+        alpha = torch.rand(clips * T, generator=g)
+        conv = F.conv1d(x.permute(0, 3, 1, 2).reshape(clips * HW, C, T), wt, bias, padding=1)
+        conv = conv.reshape(clips, HW, C, T).permute(0, 3, 1, 2).reshape(M, C)
+        al = alpha.repeat_interleave(HW)[:, None]
+        ref = (1 - al) * conv + r1                            # r1_blend False: x_s + (1 - alpha) * (conv + b)
+        A = x.permute(0, 2, 3, 1).reshape(M, C).contiguous().half().to(gpu)
+        Wp = packing.pack_conv_t3(wt.reshape(C, C, 3, 1, 1).to(gpu))
+        N = C
+        kw = dict(M=M, mode=ops.GEMM_TEMPORAL3, bias=bias.to(gpu), r1=r1.to(gpu),
+                  frame_alpha=alpha.to(gpu), rows_per_alpha=HW, r1_blend=False, conv=dict(Cin=C, T=T, HW=HW))
+    out = torch.empty(M, N, device=gpu)
+    ok = ops.gemm(A, Wp, out, probe_colstats=True, **kw)
+    # automatic choice: only grids of >= 192 tiles go to the ping-pong kernel; tile64 forces the other one
+    expect = {0: case == "plain_r1_persistent", 2: True, 6: False}[gemm_impl]
+    assert ok == expect, f"colstats support: got {ok}, expected {expect}"
+    cs = torch.full((2 * (M // 64), N), float("nan"), device=gpu)
+    if not ok:
+        with pytest.raises(Exception, match="colstats"):
+            ops.gemm(A, Wp, out, colstats=cs, **kw)
+        return
+    ops.gemm(A, Wp, out, colstats=cs, **kw)
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < TOL_F32
+    want = _colsum_ref(out.cpu())                              # sums of what was actually stored
+    assert not torch.isnan(cs).any()
+    assert rel_l2(cs[0::2], want[0::2]) < 2e-6 and rel_l2(cs[1::2], want[1::2]) < 2e-6
+    # statistics from the sums == statistics from a pass over the tensor (32 groups; one instance per
+    # 256 rows, and the whole tensor as one instance)
+    for rows in (256, M):
+        ninst = M // rows
+        st_a = torch.empty(ninst * 64, device=gpu)
+        st_b = torch.empty(ninst * 64, device=gpu)
+        ops.groupnorm_stats_from_colsums(cs, N, None, 0, M, rows, 1e-5, st_a)
+        nch = ops.gn_nchunks(rows, ninst)
+        partial = torch.empty(ninst * nch * 64, dtype=torch.float64, device=gpu)
+        ops.groupnorm_stats(out, None, rows, 1e-5, partial, st_b, nch)
+        torch.cuda.synchronize()
+        assert torch.allclose(st_a, st_b, rtol=2e-5, atol=2e-6), f"rows={rows}: {(st_a - st_b).abs().max()}"
+
+
+def test_groupnorm_stats_from_colsums_virtual_concat(gpu):
+    """[x1 | x2] with separate column sums (decoder skip concat), group boundaries inside and across the
+    two sources, vs torch GroupNorm statistics; bad geometry is refused."""
+    from gcd_amd import ops
+    g = _gen(32)
+    frames, HW, C1, C2 = 3, 128, 640, 320
+    M = frames * HW
+    x = torch.randn(M, C1 + C2, generator=g) * 2 + torch.randn(C1 + C2, generator=g)
+    cs1 = _colsum_ref(x[:, :C1]).float().to(gpu)
+    cs2 = _colsum_ref(x[:, C1:]).float().to(gpu)
+    stats = torch.empty(frames * 64, device=gpu)
+    ops.groupnorm_stats_from_colsums(cs1, C1, cs2, C2, M, HW, 1e-6, stats)
+    torch.cuda.synchronize()
+    xg = x.double().reshape(frames, HW, 32, (C1 + C2) // 32)
+    mean = xg.mean((1, 3))
+    rstd = 1.0 / torch.sqrt(xg.var((1, 3), unbiased=False) + 1e-6)
+    got = stats.cpu().reshape(frames, 32, 2).double()
+    assert torch.allclose(got[..., 0], mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(got[..., 1], rstd, rtol=1e-5, atol=1e-6)
+    with pytest.raises(Exception, match="64-row"):
+        ops.groupnorm_stats_from_colsums(cs1, C1, cs2, C2, M, 96, 1e-6, torch.empty(4 * 64, device=gpu))
+
+
 @pytest.mark.parametrize("M,C", [(100, 64), (1000, 320), (77, 640), (64, 1280)])
 def test_layernorm(gpu, M, C):
     from gcd_amd import ops
@@ -551,7 +655,8 @@ def test_attention_temporal(gpu, clips, T, HW, heads):
 
 # ----------------------------------------------------------------------------------- small pieces
 @pytest.mark.parametrize("M,N,K", [(28, 1280, 320), (28, 1280, 1280), (14, 320, 1280), (2, 64, 1024),
-                                   (28, 100, 768), (28, 1280, 128), (5, 33, 20), (16, 48, 260)])
+                                   (28, 100, 768), (28, 1280, 128), (5, 33, 20), (16, 48, 260),
+                                   (56, 1280, 320), (33, 64, 128), (100, 48, 64)])   # M > 32: two clips under CFG
 def test_linear_smallm(gpu, M, N, K):
     from gcd_amd import ops
     g = _gen(12)
