@@ -75,6 +75,19 @@ SIGNATURES = {
     "gcd_cfg_euler_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _vp]),
     "gcd_edm_scalings": (_i, [_vp, _vp, _vp, _i, _vp]),
     "gcd_timestep_embedding": (_i, [_vp, _vp, _i, _i, _f, _vp]),
+    "gcd_im2col3x3_f16": (_i, [_vp, _i64, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "gcd_col2im3x3_f32": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "gcd_im2col_t3_f16": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
+    "gcd_col2im_t3_f32": (_i, [_vp, _vp, _i64, _i64, _i, _i, _i, _vp]),
+    "gcd_rowblock_sum_f32": (_i, [_vp, _i64, _i64, _i, _i64, _vp, _vp]),
+    "gcd_groupnorm_bwd": (_i, [_vp, _i64, _vp, _i64, _i, _i64, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i64, _vp]),
+    "gcd_layernorm_bwd": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp, _f, _vp, _i64, _vp, _vp, _vp]),
+    "gcd_geglu_fwd_f32": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),
+    "gcd_geglu_bwd_f32": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _vp]),
+    "gcd_softmax_bwd_rows": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _f, _vp]),
+    "gcd_attn_temporal_bwd": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "gcd_cast_scale_f32_f16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _f, _vp]),
+    "gcd_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "gcd_graph_begin_capture": (_i, [_vp]),
     "gcd_graph_end_capture": (_i, [_vp, C.POINTER(_vp)]),
     "gcd_graph_launch": (_i, [_vp, _vp]),

@@ -256,6 +256,60 @@ int gcd_edm_scalings(const float* sig, float* c_in, float* c_noise, int N, void*
 int gcd_timestep_embedding(const float* t, float* emb, int N, int dim, float max_period,
                            void* stream);
 
+/* ---- fine-tune step: backward pass (BASELINE.json cfg4) ----------------------------------------- */
+/* The reference trains the same VideoUNet through torch.autograd (loss.py:115-273 forward,
+ * Lightning backward, diffusion.py:412-431 optimizer).  The contractions of the backward pass run on
+ * gcd_gemm_f16 with transposed operands; these are the kernels around them (gcd_amd/csrc/backward.hip).
+ * fp32 gradients, row-major with explicit leading dimensions, like the forward.                       */
+/* 3x3 taps of x16 [frames*Hi*Wi, Cin] laid out as the implicit GEMM's A operand: col16 [frames*Ho*Wo,
+ * 9*Cin], K order (kh, kw, cin) — the wgrad operand of Conv2d 3x3 (openaimodel.py:270-274,299-307),
+ * stride 1 / 2, fused x2 upsample, asymmetric padding as gcd_gemm_f16's CONV3X3 mode.                */
+int gcd_im2col3x3_f16(const void* x16, int64_t ldx, void* col16, int frames, int Cin, int Hi, int Wi,
+                      int Ho, int Wo, int stride, int upsample, int asym_pad, void* stream);
+/* dx [frames*Hi*Wi, Cin] = transpose of the above applied to dcol fp32 [frames*Ho*Wo, 9*Cin] (the dgrad
+ * of the convolution once dcol = dY @ W has been formed by a plain GEMM); a gather, deterministic.   */
+int gcd_col2im3x3_f32(const float* dcol, float* dx, int64_t lddx, int frames, int Cin, int Hi, int Wi,
+                      int Ho, int Wo, int stride, int upsample, int asym_pad, void* stream);
+/* The same pair for the (3,1,1) temporal convolution of time_stack (video_model.py:42-60): rows are
+ * (clip, t, hw), col [M, 3*C] in K order (kt, cin).                                                  */
+int gcd_im2col_t3_f16(const void* x16, int64_t ldx, void* col16, int64_t M, int C, int T, int HW,
+                      void* stream);
+int gcd_col2im_t3_f32(const float* dcol, float* dx, int64_t lddx, int64_t M, int C, int T, int HW,
+                      void* stream);
+/* out[b][n] += sum of x over rows b*rows_per_block .. +rows_per_block-1 (out zeroed by the caller):
+ * bias gradients (one block) and the gradients of per-frame epilogue vectors (emb_layers output).    */
+int gcd_rowblock_sum_f32(const float* x, int64_t ldx, int64_t M, int N, int64_t rows_per_block,
+                         float* out_zeroed, void* stream);
+/* GroupNorm(32) [+SiLU] backward: x, dy, dx fp32 [M, C]; stats from gcd_groupnorm_stats; AB_zeroed:
+ * ninst*C*2 doubles that receive per (instance, channel) sum(dz), sum(dz*xhat) — dbeta / dgamma are
+ * their sums over instances.  Replaces autograd of util.py:259-276 + SiLU.                           */
+int gcd_groupnorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int C, int64_t M,
+                      int64_t rows_per_inst, const float* stats, const float* gamma, const float* beta,
+                      int silu, double* AB_zeroed, float* dx, int64_t lddx, void* stream);
+/* LayerNorm backward (rows of C <= 1280): dx, and dgamma / dbeta accumulated into zeroed [C] buffers. */
+int gcd_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t M, int C,
+                      const float* gamma, float eps, float* dx, int64_t lddx, float* dgamma_zeroed,
+                      float* dbeta_zeroed, void* stream);
+/* GEGLU on the fp32 projection h = [value | gate] [M, 2H] (attention.py:87-97): out = value*gelu(gate)
+ * (exact erf) and its backward.                                                                      */
+int gcd_geglu_fwd_f32(const float* h, int64_t ldh, float* out, int64_t ldo, int64_t M, int H, void* stream);
+int gcd_geglu_bwd_f32(const float* h, int64_t ldh, const float* dout, int64_t lddo, float* dh, int64_t lddh,
+                      int64_t M, int H, void* stream);
+/* Softmax backward over R rows of S scores: dS16 = P16 * (dP - rowsum(P16*dP)) * scale.              */
+int gcd_softmax_bwd_rows(const void* P16, int64_t ldp, const float* dP, int64_t lddp, void* dS16,
+                         int64_t ldds, int64_t R, int S, float scale, void* stream);
+/* Backward of gcd_attn_temporal_f16 (T <= 16 tokens, d = 64): dqkv fp32 [M, 3C] from dO fp32 [M, C].  */
+int gcd_attn_temporal_bwd(const void* qkv16, int64_t ld, const float* dO, int64_t lddo, float* dqkv,
+                          int64_t lddq, int clips, int T, int HW, int heads, void* stream);
+/* y16 = fp16(x * scale): gradients enter the fp16 GEMMs pre-scaled (loss scaling), the GEMM's s_acc
+ * removes the factor in fp32.                                                                        */
+int gcd_cast_scale_f32_f16(const float* x, int64_t ldx, void* y16, int64_t ldy, int64_t M, int C,
+                           float scale, void* stream);
+/* torch.optim.Adam step (no amsgrad; weight_decay added to the gradient), in place; grad_scale is
+ * multiplied into g first (1 / loss_scale, 1 / world_size ...).  diffusion.py:412-431.                */
+int gcd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
 /* ---- stream / graph plumbing ---------------------------------------------------------------- */
 int gcd_graph_begin_capture(void* stream);
 int gcd_graph_end_capture(void* stream, void** graph_exec_out);

@@ -1,0 +1,388 @@
+"""GPU: gradient parity of the fine-tune step's HIP operators (gcd_amd.autograd_ops, through the C ABI)
+with torch.autograd — per operator against plain fp32 torch on the CPU, per block and for a whole
+TINY-width VideoUNet training step against torch.autograd over the CPU oracle (oracle/svd_unet_ref.py),
+then the optimizer step (BASELINE.json cfg4).
+
+Operands are fp16 with fp32 accumulation in both directions (activations and incoming gradients are
+rounded once per contraction), so per-operator gradients carry ~2^-11 relative noise per operand:
+tolerance 3e-3 rel-L2 per operator, 5e-3 on the gradients of whole blocks / the whole network, as
+measured values are printed."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+from oracle import svd_unet_ref as O, weights
+
+pytestmark = pytest.mark.gpu
+TOL_OP = 3e-3
+TOL_NET = 5e-3
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _leaf(t, gpu=None):
+    t = t.clone().to(gpu) if gpu is not None else t.clone()
+    return t.requires_grad_(True)
+
+
+def _tok(x):            # [n, c, h, w] -> [n*h*w, c]
+    n, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(n * h * w, c).contiguous()
+
+
+def _untok(t, n, h, w):
+    return t.reshape(n, h, w, -1).permute(0, 3, 1, 2)
+
+
+def _check(name, got, ref, tol=TOL_OP):
+    e = rel_l2(got, ref)
+    print(f"  {name}: rel-L2 {e:.2e}")
+    assert e < tol, f"{name}: rel-L2 {e:.3e}"
+
+
+# ------------------------------------------------------------------------------------------ operators
+@pytest.mark.parametrize("M,K,N,bias", [(300, 64, 128, True), (28, 256, 64, True), (1000, 320, 48, False)])
+def test_linear_backward(gpu, M, K, N, bias):
+    from gcd_amd import autograd_ops as A
+    g = _gen(1)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    xr, wr, br = _leaf(x), _leaf(w), _leaf(b)
+    F.linear(xr, wr, br if bias else None).backward(dy)
+    xg, wg, bg = _leaf(x, gpu), _leaf(w, gpu), _leaf(b, gpu)
+    y = A.linear(xg, wg, bg if bias else None)
+    _check("y", y, F.linear(x, w, b if bias else None))
+    y.backward(dy.to(gpu))
+    _check("dx", xg.grad, xr.grad)
+    _check("dw", wg.grad, wr.grad)
+    if bias:
+        _check("db", bg.grad, br.grad, 1e-5)
+
+
+@pytest.mark.parametrize("frames,H,W,Cin,Cout,stride,up", [
+    (2, 8, 8, 64, 64, 1, False), (3, 6, 10, 64, 128, 2, False), (2, 4, 6, 128, 64, 1, True),
+    (2, 8, 8, 8, 64, 1, False), (2, 8, 8, 64, 4, 1, False)])
+def test_conv3x3_backward(gpu, frames, H, W, Cin, Cout, stride, up):
+    from gcd_amd import autograd_ops as A
+    g = _gen(2)
+    x = torch.randn(frames, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = _leaf(x), _leaf(w), _leaf(b)
+    inp = F.interpolate(xr, scale_factor=2, mode="nearest") if up else xr
+    yr = F.conv2d(inp, wr, br, stride=stride, padding=1)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    xg, wg, bg = _leaf(_tok(x), gpu), _leaf(w, gpu), _leaf(b, gpu)
+    y = A.conv3x3(xg, wg, bg, frames, H, W, stride=stride, upsample=up)
+    _check("y", y, _tok(yr))
+    y.backward(_tok(dy).to(gpu))
+    _check("dx", xg.grad, _tok(xr.grad))
+    _check("dw", wg.grad, wr.grad)
+    _check("db", bg.grad, br.grad, 1e-5)
+
+
+@pytest.mark.parametrize("clips,T,HW,C", [(2, 5, 12, 64), (1, 14, 16, 128)])
+def test_conv_t3_backward(gpu, clips, T, HW, C):
+    from gcd_amd import autograd_ops as A
+    g = _gen(3)
+    x = torch.randn(clips, C, T, HW, 1, generator=g)
+    w = torch.randn(C, C, 3, 1, 1, generator=g) / math.sqrt(3 * C)
+    b = torch.randn(C, generator=g)
+    xr, wr, br = _leaf(x), _leaf(w), _leaf(b)
+    yr = F.conv3d(xr, wr, br, padding=(1, 0, 0))
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    tok = lambda t: t[..., 0].permute(0, 2, 3, 1).reshape(clips * T * HW, C).contiguous()   # noqa: E731
+    xg, wg, bg = _leaf(tok(x), gpu), _leaf(w, gpu), _leaf(b, gpu)
+    y = A.conv_t3(xg, wg, bg, T, HW)
+    _check("y", y, tok(yr))
+    y.backward(tok(dy).to(gpu))
+    _check("dx", xg.grad, tok(xr.grad))
+    _check("dw", wg.grad, wr.grad)
+    _check("db", bg.grad, br.grad, 1e-5)
+
+
+@pytest.mark.parametrize("frames,HW,C,per_clip_T,silu", [(4, 64, 64, 0, True), (4, 50, 320, 2, True), (3, 33, 128, 0, False)])
+def test_groupnorm_backward(gpu, frames, HW, C, per_clip_T, silu):
+    from gcd_amd import autograd_ops as A
+    g = _gen(4)
+    x = torch.randn(frames * HW, C, generator=g) * 2 + 0.7
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    dy = torch.randn(frames * HW, C, generator=g)
+    rows = (per_clip_T or 1) * HW
+    xr, gr, br = _leaf(x), _leaf(gamma), _leaf(beta)
+    xn = xr.reshape(frames * HW // rows, rows, C).permute(0, 2, 1)
+    yr = F.group_norm(xn, 32, gr, br, 1e-5)
+    yr = (F.silu(yr) if silu else yr).permute(0, 2, 1).reshape(frames * HW, C)
+    yr.backward(dy)
+    xg, gg, bg = _leaf(x, gpu), _leaf(gamma, gpu), _leaf(beta, gpu)
+    y = A.group_norm(xg, gg, bg, rows, 1e-5, silu)
+    _check("y", y, yr, 6e-4)
+    y.backward(dy.to(gpu))
+    _check("dx", xg.grad, xr.grad, 1e-4)
+    _check("dgamma", gg.grad, gr.grad, 1e-4)
+    _check("dbeta", bg.grad, br.grad, 1e-4)
+
+
+@pytest.mark.parametrize("M,C", [(100, 64), (500, 320), (33, 1280)])
+def test_layernorm_backward(gpu, M, C):
+    from gcd_amd import autograd_ops as A
+    g = _gen(5)
+    x = torch.randn(M, C, generator=g) * 1.5 + 0.3
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    dy = torch.randn(M, C, generator=g)
+    xr, gr, br = _leaf(x), _leaf(gamma), _leaf(beta)
+    F.layer_norm(xr, (C,), gr, br, 1e-5).backward(dy)
+    xg, gg, bg = _leaf(x, gpu), _leaf(gamma, gpu), _leaf(beta, gpu)
+    A.layer_norm(xg, gg, bg).backward(dy.to(gpu))
+    _check("dx", xg.grad, xr.grad, 1e-4)
+    _check("dgamma", gg.grad, gr.grad, 1e-4)
+    _check("dbeta", bg.grad, br.grad, 1e-4)
+
+
+def test_geglu_backward(gpu):
+    from gcd_amd import autograd_ops as A
+    g = _gen(6)
+    h = torch.randn(200, 512, generator=g) * 1.5
+    dout = torch.randn(200, 256, generator=g)
+    hr = _leaf(h)
+    a, gate = hr.chunk(2, dim=-1)
+    yr = a * F.gelu(gate)
+    yr.backward(dout)
+    hg = _leaf(h, gpu)
+    y = A.geglu(hg)
+    _check("y", y, yr, 1e-5)
+    y.backward(dout.to(gpu))
+    _check("dh", hg.grad, hr.grad, 1e-5)
+
+
+@pytest.mark.parametrize("frames,S,heads", [(2, 64, 2), (1, 128, 1), (2, 16, 1), (1, 100, 2)])
+def test_spatial_attention_backward(gpu, frames, S, heads):
+    from gcd_amd import autograd_ops as A
+    g = _gen(7)
+    C = heads * 64
+    qkv = torch.randn(frames * S, 3 * C, generator=g)
+    dO = torch.randn(frames * S, C, generator=g)
+    qr = _leaf(qkv)
+    q, k, v = (t.reshape(frames, S, heads, 64).transpose(1, 2) for t in qr.chunk(3, dim=-1))
+    yr = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(frames * S, C)
+    yr.backward(dO)
+    qg = _leaf(qkv, gpu)
+    y = A.spatial_attention(qg, frames, S, heads)
+    _check("out", y, yr, 1.5e-3)
+    y.backward(dO.to(gpu))
+    _check("dqkv", qg.grad, qr.grad)
+
+
+@pytest.mark.parametrize("clips,T,HW,heads", [(2, 14, 6, 2), (1, 4, 33, 1), (1, 16, 5, 3)])
+def test_temporal_attention_backward(gpu, clips, T, HW, heads):
+    from gcd_amd import autograd_ops as A
+    g = _gen(8)
+    C = heads * 64
+    M = clips * T * HW
+    qkv = torch.randn(M, 3 * C, generator=g)
+    dO = torch.randn(M, C, generator=g)
+    qr = _leaf(qkv)
+    # rows (clip, t, hw) -> batch (clip, hw), tokens t
+    q, k, v = (t.reshape(clips, T, HW, heads, 64).permute(0, 2, 3, 1, 4) for t in qr.chunk(3, dim=-1))
+    yr = F.scaled_dot_product_attention(q, k, v).permute(0, 3, 1, 2, 4).reshape(M, C)
+    yr.backward(dO)
+    qg = _leaf(qkv, gpu)
+    y = A.temporal_attention(qg, clips, T, HW, heads)
+    _check("out", y, yr, 1.5e-3)
+    y.backward(dO.to(gpu))
+    _check("dqkv", qg.grad, qr.grad, 1e-3)      # fp32 backward on fp16-rounded q, k, v
+
+
+def test_adam_step_vs_torch(gpu):
+    from gcd_amd.training import AdamHIP
+    g = _gen(9)
+    shapes = [(300, 7), (5,), (64, 64)]
+    ps = [torch.randn(s, generator=g) for s in shapes]
+    ref = [torch.nn.Parameter(p.clone()) for p in ps]
+    mine = [torch.nn.Parameter(p.clone().to(gpu)) for p in ps]
+    opt_r = torch.optim.Adam(ref, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    opt_m = AdamHIP(mine, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    for step in range(4):
+        grads = [torch.randn(s, generator=g) for s in shapes]
+        for p, q, gr in zip(ref, mine, grads):
+            p.grad = gr.clone()
+            q.grad = (gr * 64.0).to(gpu)               # a loss scale that the step removes
+        opt_r.step()
+        opt_m.step(grad_scale=1.0 / 64.0)
+    for p, q in zip(ref, mine):
+        assert rel_l2(q, p) < 1e-6
+
+
+# -------------------------------------------------------------------------------------- blocks, network
+def _tiny_unet(gpu, salt=0):
+    from gcd_amd.video_model import VideoUNet
+    with torch.device("meta"):
+        net = VideoUNet(**O.TINY.as_reference_kwargs())
+    sd = weights.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, salt)
+    net = net.to_empty(device=gpu)
+    net.load_state_dict(sd)
+    return net.train(), sd
+
+
+def _grad_dict(named, prefix=""):
+    return {prefix + k: v.grad for k, v in named if v.grad is not None}
+
+
+def test_video_resblock_and_transformer_gradients_vs_oracle(gpu):
+    """One VideoResBlock and one SpatialVideoTransformer of the TINY UNet (input_blocks.1): output,
+    input gradient and every parameter gradient vs torch.autograd over the oracle."""
+    from gcd_amd import training as TR
+    net, sd = _tiny_unet(gpu)
+    T, H, W = 4, 8, 8
+    frames = 2 * T
+    g = _gen(11)
+    C = 64
+    x = torch.randn(frames, C, H, W, generator=g)
+    emb = torch.randn(frames, 4 * C, generator=g)
+    ctx = torch.randn(frames, 1, 64, generator=g)
+    ioi = torch.zeros(2, T)
+    ioi[1, 2] = 1.0
+    # ---- VideoResBlock ----
+    p = "input_blocks.1.0"
+    sdr = {k: _leaf(v) for k, v in sd.items() if k.startswith(p)}
+    xr, er = _leaf(x), _leaf(emb)
+    yr = O._video_resblock(sdr, p, xr, er, T, ioi)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    rb = net.input_blocks[1][0]
+    xg, eg = _leaf(_tok(x), gpu), _leaf(emb, gpu)
+    y = TR._video_resblock(rb, xg, eg, frames, T, H, W, ioi.to(gpu))
+    print("VideoResBlock:")
+    _check("out", _untok(y, frames, H, W), yr, 2e-3)
+    y.backward(_tok(dy).to(gpu))
+    _check("dx", _untok(xg.grad, frames, H, W), xr.grad, TOL_NET)
+    _check("demb", eg.grad, er.grad, TOL_NET)
+    for name, prm in rb.named_parameters():
+        _check("d " + name, prm.grad, sdr[f"{p}.{name}"].grad, TOL_NET)
+    # ---- SpatialVideoTransformer ----
+    p = "input_blocks.1.1"
+    sdr = {k: _leaf(v) for k, v in sd.items() if k.startswith(p)}
+    xr, cr = _leaf(x), _leaf(ctx)
+    yr = O._spatial_video_transformer(sdr, p, xr, cr, T, ioi, O.TINY)
+    yr.backward(dy)
+    tr = net.input_blocks[1][1]
+    for prm in tr.parameters():
+        prm.grad = None
+    xg = _leaf(_tok(x), gpu)
+    y = TR._transformer(tr, xg, ctx.reshape(frames, -1).to(gpu), frames, T, H, W, ioi.to(gpu))
+    print("SpatialVideoTransformer:")
+    _check("out", _untok(y, frames, H, W), yr, 2e-3)
+    y.backward(_tok(dy).to(gpu))
+    _check("dx", _untok(xg.grad, frames, H, W), xr.grad, TOL_NET)
+    dead = 0
+    for name, prm in tr.named_parameters():
+        ref = sdr[f"{p}.{name}"].grad
+        if ref is None or float(ref.abs().max()) == 0.0:      # to_q / to_k / norm2 of the 1-key cross-attention
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, name
+            dead += 1
+            continue
+        _check("d " + name, prm.grad, ref, TOL_NET)
+    assert dead >= 8, "the one-key cross-attention's q / k / norm2 must receive exactly zero gradient"
+
+
+@pytest.mark.parametrize("step", [0, 2500])
+def test_unet_training_step_vs_oracle(gpu, step):
+    """BASELINE.json cfg4 at TINY width: denoiser + loss forward, backward through the whole VideoUNet on
+    HIP kernels, Adam step — loss, every parameter gradient and the updated parameters vs
+    torch.autograd / torch.optim.Adam over the CPU oracle.  step 0: plain mean loss (the focal top-k is
+    not active yet); step 2500: top 55 % of the per-pixel losses — which pixels are "top" is a discrete
+    choice, so a 1e-3 difference in the network output flips the membership of pixels at the threshold
+    and the gradients differ by more than operand rounding alone."""
+    from gcd_amd import training as TR
+    from oracle import loss_ref as LR
+    net, sd = _tiny_unet(gpu, salt=3)
+    T, H, W, B = 4, 16, 16, 2          # 2 x 2 tokens at the bottleneck
+    BT = B * T
+    cfg = O.TINY
+    g = _gen(12)
+    x0 = torch.randn(BT, 4, H, W, generator=g)
+    noise = torch.randn(BT, 4, H, W, generator=g)
+    cond = {"crossattn": torch.randn(BT, 1, cfg.context_dim, generator=g),
+            "concat": torch.randn(BT, 4, H, W, generator=g) * 0.8,
+            "vector": torch.randn(BT, cfg.adm_in_channels + cfg.aux_emb_dim, generator=g).clamp(-1, 1)}
+    sig = LR.harmonize(LR.edm_sigmas(torch.randn(BT, generator=g), 1.0, 1.6), T)
+    ioi = torch.zeros(B, T)
+    loss_scale = 256.0
+    # ---- oracle: fp32 CPU autograd ----
+    sdr = {k: _leaf(v) for k, v in sd.items()}
+    noised = x0 + noise * sig[:, None, None, None]
+    out_r = O.denoise(sdr, cfg, noised, sig, cond, T, ioi)
+    loss_r = LR.get_loss(out_r, x0, LR.edm_weighting(sig, 1.0)[:, None, None, None], step, "l2", 0.1, 5000).mean()
+    loss_r.backward()
+    # ---- product ----
+    den = TR.TrainDenoiser({"target": "gcd_amd.denoiser_scaling.VScalingWithEDMcNoise"})
+    loss_fn = TR.StandardDiffusionLoss(
+        sigma_sampler_config={"target": "gcd_amd.training.EDMSampling", "params": {"p_mean": 1.0, "p_std": 1.6}},
+        loss_weighting_config={"target": "gcd_amd.training.EDMWeighting", "params": {"sigma_data": 1.0}},
+        focus_top=0.1, focus_steps=5000, batch2model_keys=["image_only_indicator", "num_video_frames"])
+    cg = {k: v.to(gpu) for k, v in cond.items()}
+    sg = sig.to(gpu)
+    out = den(net, noised.to(gpu), sg, cg, num_video_frames=T, image_only_indicator=ioi.to(gpu))
+    w = loss_fn.loss_weighting(sg)[:, None, None, None]
+    loss = loss_fn.get_loss(out, x0.to(gpu), w, {"global_step": step}).mean()
+    (loss * loss_scale).backward()
+    torch.cuda.synchronize()
+    print(f"loss {float(loss):.6f} vs oracle {float(loss_r):.6f}")
+    assert abs(float(loss) / float(loss_r) - 1.0) < 2e-3
+    _check("denoiser output", out, out_r, 2e-3)
+    num = den_ = 0.0
+    worst = ("", 0.0)
+    nz = 0
+    errs = []
+    for name, prm in net.named_parameters():
+        ref = sdr[name].grad
+        if ref is None or float(ref.abs().max()) == 0.0:
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, name
+            continue
+        got = prm.grad.double().cpu() / loss_scale
+        num += float((got - ref.double()).pow(2).sum())
+        den_ += float(ref.double().pow(2).sum())
+        e = rel_l2(got, ref)
+        nz += 1
+        if ref.numel() < 64:
+            # a scalar blend logit's gradient is one long cancelling sum (sum dy (x_s - x_t)): its relative
+            # error is not bounded by operand rounding; it is covered by the global norm below
+            continue
+        errs.append((e, name))
+        if e > worst[1]:
+            worst = (name, e)
+    total = math.sqrt(num / den_)
+    errs.sort(reverse=True)
+    print(f"step {step}: parameter gradients: {nz} tensors, global rel-L2 {total:.3e}; worst: "
+          + ", ".join(f"{n} {e:.2e}" for e, n in errs[:6]))
+    tol = TOL_NET if step == 0 else 3 * TOL_NET
+    assert total < tol and worst[1] < 4 * tol
+    # ---- optimizer step (diffusion.py:412-431: Adam, lr from the config) ----
+    if step != 0:
+        return          # the update of a first Adam step is lr * sign(g): only meaningful where g is well resolved
+    lr = 1e-3
+    ref_params = [torch.nn.Parameter(sd[n].clone()) for n, _ in net.named_parameters()]
+    for rp, (n, _) in zip(ref_params, net.named_parameters()):
+        rp.grad = sdr[n].grad.clone() if sdr[n].grad is not None else torch.zeros_like(rp)
+    torch.optim.Adam(ref_params, lr=lr).step()
+    opt = TR.AdamHIP(net.parameters(), lr=lr)
+    opt.step(grad_scale=1.0 / loss_scale)
+    torch.cuda.synchronize()
+    moved = 0.0
+    for rp, (n, prm) in zip(ref_params, net.named_parameters()):
+        if prm.grad is None:
+            continue
+        # the first Adam step moves every weight by ~lr * sign(grad): compare the updates themselves
+        du, dr = prm.detach().cpu() - sd[n], rp.detach() - sd[n]
+        big = sdr[n].grad.abs() > 0.05 * sdr[n].grad.abs().max()      # sign(g) is noise where g is ~0
+        if big.any():
+            assert rel_l2(du[big], dr[big]) < 2e-2, n
+            moved += float(dr[big].abs().sum())
+    assert moved > 0

@@ -1,0 +1,136 @@
+"""CPU: host side of the fine-tune step (BASELINE.json cfg4): the training loss
+against known answers from the unmodified reference classes (oracle/make_golden_loss.py), its oracle
+restatement, the plugin socket, and the data-parallel gradient exchange over gloo (world size 2)."""
+import os
+import socket
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import rel_l2
+from oracle import loss_ref as R
+
+GOLD = Path(__file__).resolve().parent / "golden" / "loss_kat.pt"
+CFG = dict(
+    harmonize_sigmas=True, focus_top=0.1, focus_steps=5000,
+    batch2model_keys=["image_only_indicator", "num_video_frames"],
+    loss_weighting_config={"target": "gcd_amd.training.EDMWeighting", "params": {"sigma_data": 1.0}},
+    sigma_sampler_config={"target": "gcd_amd.training.EDMSampling", "params": {"p_mean": 1.0, "p_std": 1.6}})
+
+
+@pytest.fixture(scope="module")
+def g():
+    return torch.load(GOLD)
+
+
+def test_sigma_sampling_and_weighting_vs_reference(g):
+    from gcd_amd.training import EDMSampling, EDMWeighting
+    sig = EDMSampling(p_mean=1.0, p_std=1.6)(8, rand=g["rand"])
+    assert torch.equal(sig, g["sigmas"]) and torch.equal(R.edm_sigmas(g["rand"], 1.0, 1.6), g["sigmas"])
+    assert torch.equal(EDMWeighting(sigma_data=1.0)(sig), g["weights"])
+    assert torch.equal(R.edm_weighting(sig, 1.0), g["weights"])
+    assert EDMSampling()(5).shape == (5,)
+
+
+def test_get_loss_vs_reference_known_answers(g):
+    """L2 / L1, the annealed top-fraction focal loss at steps before, inside and after the annealing
+    window (keep fraction 1 -> 0.1 over 5000 steps), EDM weighting: product and oracle vs reference."""
+    from gcd_amd.training import StandardDiffusionLoss
+    w = g["weights"][:, None, None, None]
+    for case in g["cases"]:
+        loss = StandardDiffusionLoss(**dict(CFG, loss_type=case["loss_type"]))
+        got = loss.get_loss(g["out"], g["tgt"], w, {"global_step": case["step"]})
+        ora = R.get_loss(g["out"], g["tgt"], w, case["step"], case["loss_type"], 0.1, 5000)
+        assert torch.allclose(got, case["loss"], rtol=1e-6, atol=0), case
+        assert torch.allclose(ora, case["loss"], rtol=1e-6, atol=0), case
+    with pytest.raises(NotImplementedError):
+        StandardDiffusionLoss(**dict(CFG, pd_person_weight=2.0)).get_loss(g["out"], g["tgt"], w, {"global_step": 0})
+    with pytest.raises(AssertionError):
+        StandardDiffusionLoss(**dict(CFG, loss_type="huber"))
+
+
+def test_forward_plumbing_vs_reference(g):
+    """_forward: per-clip harmonised sigmas, noised input, batch2model_keys, weighting — same global RNG
+    seed as the reference run, so the draws are identical."""
+    from gcd_amd.training import StandardDiffusionLoss
+    f = g["forward"]
+    seen = {}
+
+    def denoiser(network, noised, sigmas, cond, **kw):
+        seen.update(noised=noised.clone(), sigmas=sigmas.clone(), kw=dict(kw))
+        return noised * 0.5
+
+    T = g["T"]
+    torch.manual_seed(f["seed"])
+    batch = {"global_step": 2500, "num_video_frames": T, "image_only_indicator": torch.zeros(2, T),
+             "unrelated": 1}
+    val = StandardDiffusionLoss(**CFG)._forward(None, denoiser, {}, g["tgt"], batch)
+    assert torch.equal(seen["sigmas"], f["sigmas"]) and torch.equal(seen["noised"], f["noised"])
+    assert sorted(seen["kw"]) == f["kw_keys"]
+    assert torch.allclose(val, f["loss"], rtol=1e-6, atol=0)
+    s = seen["sigmas"].reshape(-1, T)
+    assert torch.equal(s, s[:, :1].expand_as(s))                     # one noise level per clip
+    assert torch.equal(R.harmonize(torch.arange(8.0), 4), torch.tensor([0., 0, 0, 0, 4, 4, 4, 4]))
+
+
+def test_loss_socket_instantiates_from_config():
+    from gcd_amd.util import instantiate_from_config
+    loss = instantiate_from_config({"target": "gcd_amd.training.StandardDiffusionLoss", "params": CFG})
+    assert loss.batch2model_keys == {"image_only_indicator", "num_video_frames"} and loss.focus_steps == 5000
+
+
+# ------------------------------------------------------------------------------- DDP gradient exchange
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    from gcd_amd.training import allreduce_gradients
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.zeros(s)) for s in [(300, 7), (5,), (64, 64), (1,)]]
+        frozen = torch.nn.Parameter(torch.zeros(3), requires_grad=False)
+        for i, p in enumerate(params):
+            p.grad = torch.full(p.shape, float(rank + 1) * (i + 1))
+        params[1].grad = None                                   # a parameter without gradient is skipped
+        nb = allreduce_gradients(params + [frozen], dist, bucket_bytes=4096)
+        ok = nb >= 2
+        for i, p in enumerate(params):
+            if i == 1:
+                ok = ok and p.grad is None
+            else:
+                ok = ok and torch.allclose(p.grad, torch.full(p.shape, 1.5 * (i + 1)))   # mean of ranks 1, 2
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_gradients_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == {0: True, 1: True}
+
+
+def test_allreduce_single_process_is_noop():
+    from gcd_amd.training import allreduce_gradients
+    p = torch.nn.Parameter(torch.zeros(3))
+    p.grad = torch.ones(3)
+    assert allreduce_gradients([p], None) == 0 and torch.equal(p.grad, torch.ones(3))
