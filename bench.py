@@ -209,6 +209,9 @@ def main():
     ap.add_argument("--latent", type=str, default="72x128", help="latent HxW (default 72x128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to exercise "
+                         "the multi-rank path on a box with fewer GPUs than ranks, with GCD_BENCH_SHARE_GPU=1)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed regions of --steps steps each: the first is the reported one (driver "
                          "contract), all of them feed timing_stats (median)")
@@ -234,13 +237,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product")
-    dev = torch.device("cuda", local_rank)
+    share = os.environ.get("GCD_BENCH_SHARE_GPU") == "1"     # test rig: every rank on cuda:0 (gloo only)
+    dev = torch.device("cuda", 0 if share else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            if share:
+                raise SystemExit("GCD_BENCH_SHARE_GPU=1 needs --backend gloo (RCCL wants one GPU per rank)")
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from gcd_amd import _lib, ops
     from gcd_amd.denoiser import Denoiser
@@ -378,7 +387,8 @@ def main():
                              "ms_per_step_median": round(region_ms[len(region_ms) // 2], 3),
                              "reported_region": "first (max over ranks)"},
             "per_rank_ms_per_step": [round(float(t[0]) * 1e3 / args.steps, 3) for t in per_rank],
-            "rccl_ranks": world if dist is not None else 0,
+            "rccl_ranks": world if (dist is not None and args.backend == "nccl") else 0,
+            "dist_backend": args.backend if dist is not None else None,
             "gather_ms": round(gather_ms, 3), "gathered_shape": list(gathered.shape),
             "output_finite": finite,
             "workspace_gib": round(net.engine.ws.nbytes() / 2 ** 30, 2),
