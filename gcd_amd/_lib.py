@@ -41,7 +41,7 @@ class GemmDesc(C.Structure):
         ("ln_addvec", C.c_void_p), ("ld_ln_addvec", C.c_int64), ("ln_sum_out", C.c_void_p),
         ("ld_ln_sum", C.c_int64),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("asym_pad", C.c_int32),
-        ("colstats", C.c_void_p),
+        ("colstats", C.c_void_p), ("out_blocked", C.c_int32), ("a_blocked", C.c_int32),
     ]
 
 
@@ -56,6 +56,7 @@ SIGNATURES = {
     "gcd_gemm_f16": (_i, [C.POINTER(GemmDesc), _vp]),
     "gcd_gemm_ln_fusable": (_i, [_i, _i, _i, _i]),
     "gcd_gemm_colstats_supported": (_i, [C.POINTER(GemmDesc)]),
+    "gcd_gemm_hidden_blocked_supported": (_i, [_i, _i, _i]),
     "gcd_groupnorm_stats_from_colsums": (_i, [_vp, _i, _vp, _i, _i64, _i64, _f, _vp, _vp]),
     "gcd_linear_smallm_f32": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "gcd_groupnorm_stats": (_i, [_vp, _i64, _i, _vp, _i64, _i, _i64, _i64, _f, _vp, _i, _vp, _vp]),

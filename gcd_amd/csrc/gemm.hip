@@ -428,6 +428,8 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
   k.splitk = 1;
   k.split_stride = 0;
   k.colstats = d->colstats;
+  k.out_blocked = d->out_blocked ? 1 : 0;
+  k.a_blocked = d->a_blocked ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
 
   // kernel choice: the 256 x 320 ping-pong kernel whenever the grid fills most of the chip with
@@ -460,12 +462,23 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
                   "gcd_gemm_f16: colstats cannot be honoured for this descriptor (M=%d N=%d; see "
                   "gcd_gemm_colstats_supported)", d->M, d->N);
 
+  if (d->out_blocked)
+    GCD_CHECK_ARG(use_pp && d->out_kind == GCD_OUT_GEGLU && d->M % 256 == 0 && d->N % 320 == 0,
+                  "gcd_gemm_f16: out_blocked needs a GEGLU output, M %% 256 == 0, N %% 320 == 0 and the "
+                  "ping-pong kernel (M=%d N=%d)", d->M, d->N);
+  if (d->a_blocked)
+    GCD_CHECK_ARG(use_pp && d->mode == GCD_GEMM_PLAIN && d->M % 256 == 0 && d->K % 160 == 0 &&
+                      !d->colstats && !d->ln_out16,
+                  "gcd_gemm_f16: a_blocked needs PLAIN mode, M %% 256 == 0, K %% 160 == 0, no colstats / "
+                  "fused LayerNorm and the ping-pong kernel (M=%d K=%d)", d->M, d->K);
+
   // mode-specific geometry, checked BEFORE any kernel choice (split-K included): a malformed conv /
   // temporal descriptor must come back as an argument error, never reach a gather
   if (const int rc = validate_geometry(d)) return rc;
 
   // split-K: few 256x320 tiles (<= 96 of 256 CUs) and a long K — the 3x3 convs of the 9x16 level
-  if (d->workspace && !d->ln_out16 && !d->colstats && d->out_kind != GCD_OUT_GEGLU && (impl == 0 || impl == 7) &&
+  if (d->workspace && !d->ln_out16 && !d->colstats && !d->a_blocked && d->out_kind != GCD_OUT_GEGLU &&
+      (impl == 0 || impl == 7) &&
       gcd_gemm_pp_supported(k, d->mode) && d->N >= 160 && d->N % 4 == 0) {
     const int64_t tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 319) / 320);
     int splitk = (int)(256 / tiles);
@@ -496,6 +509,17 @@ extern "C" int gcd_gemm_colstats_supported(const gcd_gemm_desc* d) {
   if (impl == 1 || impl == 5 || impl == 6) return 0;          // general kernel forced
   const int64_t tiles = (int64_t)(d->M / 256) * (d->N / 320);
   if ((impl == 0 || impl == 7) && tiles < 192) return 0;      // automatic choice: general kernel / split-K
+  return 1;
+}
+
+extern "C" int gcd_gemm_hidden_blocked_supported(int M, int N_geglu, int N_out) {
+  if (M <= 0 || M % 256 != 0 || N_geglu <= 0 || N_geglu % 320 != 0 || N_out < 160 || N_out % 16 != 0) return 0;
+  const int impl = gcd_tune_get(GCD_TUNE_GEMM_IMPL);
+  if (impl == 1 || impl == 5 || impl == 6) return 0;          // general kernel forced
+  if (impl == 0 || impl == 7) {                                // automatic choice: both grids must be large
+    const int64_t t1 = (int64_t)(M / 256) * (N_geglu / 320), t2 = (int64_t)(M / 256) * ((N_out + 319) / 320);
+    if (t1 < 192 || t2 < 192) return 0;
+  }
   return 1;
 }
 

@@ -44,6 +44,7 @@ struct GemmK {
   // per-64-row column sums / sums of squares of the fp32 output for the next GroupNorm
   // (gcd_gemm_desc.colstats): [2 * M / 64, N]
   float* colstats;
+  int out_blocked, a_blocked;   // tile-blocked GEGLU hidden tensor (gcd_gemm_desc.out_blocked / a_blocked)
 };
 
 // gemm_pp.hip: the 256 x 320 ping-pong kernel.
@@ -322,13 +323,21 @@ __device__ __forceinline__ void gcd_epi_geglu_rows_full(const GemmK& p, f32x16 (
           o[e] = (f16)((acc[i][j][4 * g + e] + ba[e]) * gelu_fast(acc[i][j][8 + 4 * g + e] + bg[e]));
         *(f16x4*)(stage + (32 * j + l31) * GCD_EPI_ROW_F16 + (16 * i + 8 * g + 4 * hh) * 2) = o;
       }
-  f16* const outp = (f16*)p.out + (int64_t)m_base * p.ldo + (n_base >> 1);
+  // row-major [M, N/2], or tile-blocked: tile (tm, tn) = one contiguous [256][160] block (out_blocked)
+  f16* outp = (f16*)p.out + (int64_t)m_base * p.ldo + (n_base >> 1);
+  int64_t rs = p.ldo;
+  if (p.out_blocked) {
+    const int tn = n_base / 320;
+    const int64_t blk = (int64_t)(m_base >> 8) * (p.N / 320) + tn;
+    outp = (f16*)p.out + (blk * 256 + (m_base & 255)) * 160 + ((n_base - tn * 320) >> 1);
+    rs = 160;
+  }
 #pragma unroll
   for (int it = 0; it < 10; ++it) {
     const int tt = it * 64 + lane;
     const int row = tt / 10, ch = tt - row * 10;
     const f16x8 v = *(const f16x8*)(stage + row * GCD_EPI_ROW_F16 + ch * 16);
-    *(f16x8*)(outp + (int64_t)row * p.ldo + ch * 8) = v;
+    *(f16x8*)(outp + (int64_t)row * rs + ch * 8) = v;
   }
 }
 

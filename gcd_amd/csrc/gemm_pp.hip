@@ -63,6 +63,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
   // Each XCD owns a contiguous range of the linear tile order.  One tile per workgroup, or (VAR bit
   // 2048, persistent) 32 workgroups per XCD that walk their XCD's range with stride 32.
   constexpr bool PERSIST = (VAR & 2048) != 0;
+  // A operand tile-blocked in 160-column blocks ([M/256][K/160][256][160], the GEGLU hidden tensor as
+  // out_blocked wrote it): PLAIN mode only, own instantiation so the plain K walk keeps its address math
+  constexpr bool ABLK = MODE == GCD_GEMM_PLAIN && (VAR & 32) != 0 && !(VAR & 31);
   int L, L_end, L_step;
   {
     const int nblk = PERSIST ? p.tiles_m * p.tiles_n : (int)gridDim.x, bid = blockIdx.x;
@@ -153,7 +156,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
       a_fb[i] = 0;
       a_base[i] = nullptr;
       a_inc[i] = 2;
-      if (MODE == GCD_GEMM_PLAIN) {
+      if (MODE == GCD_GEMM_PLAIN && ABLK) {
+        a_base[i] = (const char*)p.A + ((int64_t)(m >> 8) * (p.K / 160) * 256 + (m & 255)) * 320 + lc16;
+      } else if (MODE == GCD_GEMM_PLAIN) {
         a_base[i] = (const char*)p.A + (int64_t)m * p.lda * 2 + lc16;
       } else if (MODE == GCD_GEMM_CONV3X3) {
         const int hw = p.Ho * p.Wo;
@@ -200,7 +205,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
   auto issue_A = [&](int sigma) {
     if (sigma < S && dma_on) {
       char* dst = smem + (sigma & 3) * PP_SLOT + wave * 2048;
-      if (MODE == GCD_GEMM_PLAIN) {
+      if (MODE == GCD_GEMM_PLAIN && ABLK) {
+        const int sg = s_begin + sigma, kb = sg / 5;          // 5 sub-tiles of 32 columns per 160-column block
+        const int off = kb * (256 * 320) + (sg - 5 * kb) * 64;
+        glds16(a_base[0] + off, dst);
+        glds16(a_base[1] + off, dst + 1024);
+      } else if (MODE == GCD_GEMM_PLAIN) {
         glds16(a_base[0] + (s_begin + sigma) * 64, dst);
         glds16(a_base[1] + (s_begin + sigma) * 64, dst + 1024);
       } else {
@@ -574,6 +584,8 @@ int gcd_gemm_pp_launch(const GemmK& k, int mode, hipStream_t s) {
     }
     return persist ? launch_pp<GCD_GEMM_PLAIN, 2048 + 8192>(k, s) : launch_pp<GCD_GEMM_PLAIN, 8192>(k, s);
   }
+  if (k.a_blocked)    // validated by gcd_gemm_f16: PLAIN mode, no colstats / LayerNorm / split-K
+    return persist ? launch_pp<GCD_GEMM_PLAIN, 2048 + 32>(k, s) : launch_pp<GCD_GEMM_PLAIN, 32>(k, s);
   if (k.colstats) {   // validated by gcd_gemm_f16 (colstats_shape_ok)
     switch (mode) {
       case GCD_GEMM_PLAIN:

@@ -416,9 +416,12 @@ class UNetEngine:
     def _ff(self, F, a16, M, **epi):
         ws = self.ws
         hid = ws.alloc((M, F["w1"].shape[0] // 2), torch.float16)
-        ops.gemm(a16, F["w1"], hid, M=M, bias=F["b1"], out_kind=OUT_GEGLU)
+        # the hidden tensor only lives between these two GEMMs: where both run on the ping-pong kernel it
+        # is kept tile-blocked ([M/256][N/320][256][160]: whole 128-byte lines per store, §7 of DESIGN.md)
+        blocked = epi.get("ln") is None and ops.gemm_hidden_blocked_ok(M, F["w1"].shape[0], F["w2"].shape[0])
+        ops.gemm(a16, F["w1"], hid, M=M, bias=F["b1"], out_kind=OUT_GEGLU, out_blocked=blocked)
         ws.release(a16)
-        ops.gemm(hid, F["w2"], epi.pop("out"), M=M, bias=F["b2"], **epi)
+        ops.gemm(hid, F["w2"], epi.pop("out"), M=M, bias=F["b2"], a_blocked=blocked, **epi)
         ws.release(hid)
 
     def _transformer(self, L, x, st):

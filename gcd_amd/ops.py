@@ -120,7 +120,8 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mod
          out_kind: int = OUT_F32, bias=None, rowvec=None, rows_per_vec: int = 1, r1=None, r2=None,
          s_acc: float = 1.0, s_r1: float = 1.0, s_r2: float = 1.0, frame_alpha=None,
          rows_per_alpha: int = 1, r1_blend: bool = False, conv=None,
-         alg_flops_scale: float = 1.0, ln=None, colstats=None, probe_colstats: bool = False):
+         alg_flops_scale: float = 1.0, ln=None, colstats=None, probe_colstats: bool = False,
+         out_blocked: bool = False, a_blocked: bool = False):
     """out = epilogue(A @ W^T); see gcd_gemm_desc in include/gcd_amd.h.
 
     conv: dict(Cin, Hi, Wi, Ho, Wo, stride, upsample) for GEMM_CONV3X3 or dict(Cin, T, HW) for
@@ -134,7 +135,7 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mod
     N, K = w16.shape
     d = GemmDesc()
     d.A, d.W, d.out = a16.data_ptr(), w16.data_ptr(), out.data_ptr()
-    d.lda, d.ldo = _ld(a16), _ld(out)
+    d.lda, d.ldo = _ld(a16), _ld(out)      # (ignored for a tile-blocked operand / output)
     d.M, d.N, d.K, d.mode = M, N, K, mode
     if mode != GEMM_PLAIN:
         d.Cin = conv["Cin"]
@@ -155,6 +156,7 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mod
     if frame_alpha is not None:
         d.frame_alpha, d.rows_per_alpha, d.r1_blend = frame_alpha.data_ptr(), rows_per_alpha, int(r1_blend)
     d.out_kind = out_kind
+    d.out_blocked, d.a_blocked = int(out_blocked), int(a_blocked)
     if ln is not None:
         # fused LayerNorm of the output rows: dict(gamma, beta, out16[, eps, addvec, rows_per_vec, sum_out])
         _need_gpu(ln["gamma"], ln["beta"], ln["out16"], ln.get("addvec"), ln.get("sum_out"))
@@ -181,6 +183,20 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mod
     with _Timed("gemm", 2.0 * M * N * K * alg_flops_scale, M=M, N=N, K=K, mode=mode):
         check(_lib.load().gcd_gemm_f16(C.byref(d), _stream()), "gcd_gemm_f16")
     return out
+
+
+# Tile-blocked GEGLU hidden tensor: implemented and bit-identical, but measured neutral in the full step
+# (112.4-112.6 ms off vs 112.5-112.8 ms on, interleaved runs; tools/store_probe.cpp's 25 % store penalty
+# for 320-byte segments does not surface inside the GEGLU GEMM), so it is off unless GCD_HIDDEN_BLOCKED=1.
+_HIDDEN_BLOCKED_ON = os.environ.get("GCD_HIDDEN_BLOCKED", "0") == "1"
+
+
+def gemm_hidden_blocked_ok(M: int, n_geglu: int, n_out: int, enabled: Optional[bool] = None) -> bool:
+    """True if a FeedForward of M tokens can (and, by the GCD_HIDDEN_BLOCKED switch, should) keep its GEGLU
+    hidden tensor tile-blocked (`gemm(..., out_blocked=True)` then `gemm(..., a_blocked=True)`;
+    gcd_gemm_hidden_blocked_supported)."""
+    on = _HIDDEN_BLOCKED_ON if enabled is None else enabled
+    return bool(on and _lib.load().gcd_gemm_hidden_blocked_supported(M, n_geglu, n_out))
 
 
 def gemm_ln_fusable(M: int, N: int, K: int, mode: int = GEMM_PLAIN) -> bool:

@@ -131,6 +131,17 @@ typedef struct gcd_gemm_desc {
      takes the row-major fast epilogue (gcd_gemm_colstats_supported); otherwise gcd_gemm_f16 fails.
      [2 * M / 64, N] floats.                                                                        */
   float* colstats;
+  /* Tile-blocked GEGLU hidden tensor (ABI v4).  A 256 x 320 GEGLU tile produces 256 rows x 160 hidden
+     columns = 320-byte row segments that are not 128-byte aligned in a row-major [M, N/2] matrix, and
+     their neighbours in the same cache lines are written by other workgroups: measured 25 % slower than
+     aligned segments (tools/store_probe.cpp).  With out_blocked (GCD_OUT_GEGLU only) tile (tm, tn) is
+     stored as one contiguous 80 KB block:  out[((tm * N/320 + tn) * 256 + r) * 160 + c];  a_blocked
+     (GCD_GEMM_PLAIN only) reads an A operand laid out that way ([M/256][K/160][256][160]), i.e. the
+     FeedForward's second Linear consumes the hidden columns in the order the first one wrote them.
+     Needs M % 256 == 0, N % 320 == 0 resp. K % 160 == 0 and the ping-pong kernel
+     (gcd_gemm_hidden_blocked_supported).                                                           */
+  int32_t out_blocked;
+  int32_t a_blocked;
 } gcd_gemm_desc;
 
 /* Replaces torch.nn.Linear / Conv2d / Conv3d forward on the hot path:
@@ -146,6 +157,10 @@ int gcd_gemm_ln_fusable(int M, int N, int K, int mode);
  * M % 256 == 0, N % 320 == 0, rowvec / frame_alpha constant over each 256-row tile, the automatic
  * kernel choice lands on the 256x320 ping-pong kernel without split-K), else 0.                  */
 int gcd_gemm_colstats_supported(const gcd_gemm_desc* desc);
+/* 1 if a FeedForward of M tokens whose GEGLU projection has N_geglu output columns (hidden = N_geglu / 2)
+ * and whose second Linear has N_out columns can keep its hidden tensor tile-blocked (out_blocked on the
+ * first GEMM, a_blocked on the second): both launches must land on the ping-pong kernel.          */
+int gcd_gemm_hidden_blocked_supported(int M, int N_geglu, int N_out);
 
 /* y[M,N] (fp32) = [y +] act_out( act_in(x[M,K]) @ W[N,K]^T + b ), fp32 weights, any M >= 1 (rows are processed 32 at a time).
  * act flags: bit0 = SiLU on input, bit1 = SiLU on output, bit2 = accumulate into y.

@@ -315,6 +315,45 @@ def test_gemm_geglu(gpu, M, C):
     assert e < TOL_F16, f"geglu rel-L2 {e:.3e}"
 
 
+def test_feedforward_tile_blocked_hidden(gpu, gemm_impl):
+    """GEGLU output written tile-blocked ([M/256][N/320][256][160]) and consumed that way by the second
+    Linear: bit-identical to the row-major pair (same products, same accumulation order), the block
+    layout itself checked against the row-major hidden tensor; unsupported shapes are refused."""
+    from gcd_amd import ops, packing
+    g = _gen(41)
+    M, C = 256 * 50, 320                         # 50 x 8 GEGLU tiles, 50 FF-out tiles
+    H = 4 * C
+    x = _h(torch.randn(M, C, generator=g)).half().to(gpu)
+    w1, b1 = packing.pack_geglu((torch.randn(2 * H, C, generator=g) / math.sqrt(C)).to(gpu),
+                                torch.randn(2 * H, generator=g).to(gpu))
+    w2 = (torch.randn(C, H, generator=g) / math.sqrt(H)).half().to(gpu)
+    b2 = torch.randn(C, generator=g).to(gpu)
+    r1 = torch.randn(M, C, generator=g).to(gpu)
+    ok = ops.gemm_hidden_blocked_ok(M, 2 * H, C, enabled=True)
+    assert ok == {0: False, 2: True, 6: False}[gemm_impl]     # 50 FF-out tiles < 192: automatic says no
+    hid = torch.empty(M, H, dtype=torch.float16, device=gpu)
+    out = torch.empty(M, C, device=gpu)
+    ops.gemm(x, w1, hid, M=M, bias=b1, out_kind=ops.OUT_GEGLU)
+    ops.gemm(hid, w2, out, M=M, bias=b2, r1=r1)
+    if not ok:
+        with pytest.raises(Exception, match="out_blocked|a_blocked"):
+            if gemm_impl == 6:
+                ops.gemm(x, w1, hid, M=M, bias=b1, out_kind=ops.OUT_GEGLU, out_blocked=True)
+            else:                                 # automatic: the GEGLU launch is large enough, FF-out is not
+                ops.gemm(hid, w2, out, M=M, bias=b2, r1=r1, a_blocked=True)
+        return
+    hid_b = torch.empty(M * H, dtype=torch.float16, device=gpu)
+    out_b = torch.empty(M, C, device=gpu)
+    ops.gemm(x, w1, hid_b.view(M, H), M=M, bias=b1, out_kind=ops.OUT_GEGLU, out_blocked=True)
+    ops.gemm(hid_b.view(M, H), w2, out_b, M=M, bias=b2, r1=r1, a_blocked=True)
+    torch.cuda.synchronize()
+    want = hid.reshape(M // 256, 256, H // 160, 160).permute(0, 2, 1, 3).reshape(-1)
+    assert torch.equal(hid_b, want), "blocked hidden layout differs from [M/256][H/160][256][160]"
+    assert torch.equal(out_b, out), "tile-blocked FeedForward differs from the row-major one"
+    with pytest.raises(Exception, match="out_blocked"):
+        ops.gemm(x[:300], w1, hid[:300], M=300, bias=b1, out_kind=ops.OUT_GEGLU, out_blocked=True)
+
+
 @pytest.mark.parametrize("frames,H,W,Cin,Cout,stride,up", [
     (3, 10, 12, 64, 64, 1, 0), (2, 9, 7, 128, 320, 1, 0), (2, 12, 16, 64, 128, 2, 0),
     (2, 9, 7, 64, 64, 2, 0), (2, 5, 6, 128, 64, 1, 1), (28, 16, 16, 64, 64, 1, 0)])
