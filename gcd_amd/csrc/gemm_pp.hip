@@ -396,6 +396,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
     constexpr int EV = ((VAR >> 6) & 31) | ((VAR & 32768) ? 32 : 0);
     const bool full = wm_base + 64 <= p.M && wn_base + 160 <= p.N && lds_bias_ok;
     const float* lb = lds_bias + 160 * wn;
+#ifdef GCD_ABLATION_BUILD
+    if (EV == 8 && full && p.out_kind == GCD_OUT_GEGLU) {
+      // ablation: the product's staged GEGLU epilogue, but every tile of a wave lands on the same 10 KB
+      // (L2-resident): prices the memory side of the stores against their issue / staging side
+      GemmK q = p;
+      q.out = (f16*)p.out + (int64_t)((blockIdx.x & 255) * 8 + wave) * 64 * 80;
+      q.ldo = 80;
+      q.out_blocked = 0;
+      gcd_epi_geglu_rows_full(q, acc, 0, 0, elane, lb, smem + wave * GCD_EPI_STAGE_BYTES);
+    } else
+#endif
     if (EV == 0 && full && p.out_kind == GCD_OUT_GEGLU && (p.ldo & 7) == 0) {
       gcd_epi_geglu_rows_full(p, acc, wm_base, wn_base, elane, lb, smem + wave * GCD_EPI_STAGE_BYTES);
     } else if (EV == 0 && full && p.out_kind == GCD_OUT_F16 && !p.R1 && !p.R2 && !p.frame_alpha &&
@@ -569,6 +580,7 @@ int gcd_gemm_pp_launch(const GemmK& k, int mode, hipStream_t s) {
       case 2048 + 128: return launch_pp<GCD_GEMM_PLAIN, 2048 + 128>(k, s);       // persistent, no stores
       case 2048 + 256: return launch_pp<GCD_GEMM_PLAIN, 2048 + 256>(k, s);       // persistent, GEGLU without GELU
       case 2048 + 384: return launch_pp<GCD_GEMM_PLAIN, 2048 + 384>(k, s);       // neither
+      case 2048 + 512: return launch_pp<GCD_GEMM_PLAIN, 2048 + 512>(k, s);       // staged GEGLU epilogue, stores to an L2-resident scratch
       default: break;
     }
   }
