@@ -78,8 +78,10 @@ def _colsum(x32: torch.Tensor, rows_per_block: Optional[int] = None) -> torch.Te
 
 
 class _PackCache:
-    """fp16 operand forms of a parameter, rebuilt when the parameter changes (optimizer steps bump
-    torch's version counter)."""
+    """fp16 operand forms of a parameter, rebuilt when the parameter changes (torch's version counter;
+    `clear()` after an optimizer step that writes through raw pointers).  Keyed by storage address and
+    shape, not by Python object: under activation checkpointing the backward pass sees the parameter
+    through a different tensor object than the forward did."""
 
     def __init__(self):
         self._d = {}
@@ -87,12 +89,12 @@ class _PackCache:
     def get(self, p: torch.Tensor, kind: str, fn):
         if not p.is_leaf:          # a temporary (e.g. the concatenated q|k|v weight): pack, do not keep
             return fn(p.detach())
-        key = (id(p), kind)
+        key = (p.data_ptr(), tuple(p.shape), kind)
         hit = self._d.get(key)
-        if hit is not None and hit[0] == p._version and hit[1] is p:
-            return hit[2]
+        if hit is not None and hit[0] == p._version:
+            return hit[1]
         v = fn(p.detach())
-        self._d[key] = (p._version, p, v)
+        self._d[key] = (p._version, v)
         return v
 
     def clear(self):
@@ -202,7 +204,8 @@ class Conv3x3(torch.autograd.Function):
         else:
             _cast16_into(dy.contiguous(), dy16[:, :Cout])
         lib = _lib.load()
-        w16 = PACK.get(weight, f"c3_{cin_p}_{cout_p}", None)             # [cout_p, 9*cin_p] (forward made it)
+        w16 = PACK.get(weight, f"c3_{cin_p}_{cout_p}",
+                       lambda w: packing.pack_conv3x3(w, cin_pad=cin_p, cout_pad=cout_p))     # [cout_p, 9*cin_p]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             wt16 = PACK.get(weight, f"c3t_{cin_p}_{cout_p}", lambda w: w16.t().contiguous())   # [9*cin_p, cout_p]

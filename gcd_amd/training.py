@@ -174,9 +174,15 @@ def _transformer(tr: SpatialVideoTransformer, x, context2d, frames, T, H, W, ioi
 
 
 def unet_forward_train(unet: VideoUNet, x: torch.Tensor, timesteps: torch.Tensor, context: torch.Tensor,
-                       y: torch.Tensor, num_video_frames: int,
-                       image_only_indicator: torch.Tensor) -> torch.Tensor:
-    """VideoUNet.forward (video_model.py:461-540) with gradients: x (N, 8, H, W) -> (N, 4, H, W)."""
+                       y: torch.Tensor, num_video_frames: int, image_only_indicator: torch.Tensor,
+                       use_checkpoint: Optional[bool] = None) -> torch.Tensor:
+    """VideoUNet.forward (video_model.py:461-540) with gradients: x (N, 8, H, W) -> (N, 4, H, W).
+
+    use_checkpoint (default: the network's own `use_checkpoint`, True in every GCD config): activation
+    checkpointing at the reference's sites — every ResBlock (openaimodel.py:326-329) and every
+    transformer (attention.py:544-546, video_attention.py:104-105; here one unit per
+    SpatialVideoTransformer): only block inputs are kept, the block is re-run on HIP kernels during the
+    backward pass.  Gradients equal the un-checkpointed run's up to the summation order of atomics."""
     ops._need_gpu(x, timesteps, context, y)
     T = num_video_frames
     N, _, H, W = x.shape
@@ -193,13 +199,20 @@ def unet_forward_train(unet: VideoUNet, x: torch.Tensor, timesteps: torch.Tensor
         emb = emb + _mlp(unet.aux_label_emb, y[:, adm:].float().contiguous())
 
     st = dict(H=H, W=W)
+    ckpt = bool(unet.use_checkpoint if use_checkpoint is None else use_checkpoint) and torch.is_grad_enabled()
+
+    def block(fn, *args):
+        if ckpt:
+            from torch.utils.checkpoint import checkpoint
+            return checkpoint(fn, *args, use_reentrant=False)
+        return fn(*args)
 
     def run(seq, h):
         for m in seq:
             if isinstance(m, VideoResBlock):
-                h = _video_resblock(m, h, emb, N, T, st["H"], st["W"], ioi)
+                h = block(_video_resblock, m, h, emb, N, T, st["H"], st["W"], ioi)
             elif isinstance(m, SpatialVideoTransformer):
-                h = _transformer(m, h, ctx2d, N, T, st["H"], st["W"], ioi)
+                h = block(_transformer, m, h, ctx2d, N, T, st["H"], st["W"], ioi)
             elif isinstance(m, Downsample):
                 h = A.conv3x3(h, m.op.weight, m.op.bias, N, st["H"], st["W"], stride=2)
                 st["H"], st["W"] = (st["H"] - 1) // 2 + 1, (st["W"] - 1) // 2 + 1
@@ -229,9 +242,10 @@ class TrainDenoiser(nn.Module):
     """Denoiser.forward (denoiser.py:23-49) over OpenAIWrapper.forward (wrappers.py:23-34) with the
     training-mode UNet underneath: `denoiser(network, input, sigma, cond, **kwargs)`."""
 
-    def __init__(self, scaling_config: Dict):
+    def __init__(self, scaling_config: Dict, use_checkpoint: Optional[bool] = None):
         super().__init__()
         self.scaling = instantiate_from_config(scaling_config)
+        self.use_checkpoint = use_checkpoint        # None: follow the network's `use_checkpoint`
 
     def forward(self, network, input, sigma, cond, **additional_model_inputs):
         unet = getattr(network, "diffusion_model", network)
@@ -244,7 +258,8 @@ class TrainDenoiser(nn.Module):
             x = torch.cat((x, concat.type_as(x)), dim=1)
         out = unet_forward_train(unet, x, c_noise.reshape(sigma_shape), cond.get("crossattn"),
                                  cond.get("vector"), additional_model_inputs["num_video_frames"],
-                                 additional_model_inputs["image_only_indicator"])
+                                 additional_model_inputs["image_only_indicator"],
+                                 use_checkpoint=self.use_checkpoint)
         return out * c_out + input * c_skip
 
 

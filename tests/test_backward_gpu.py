@@ -386,3 +386,37 @@ def test_unet_training_step_vs_oracle(gpu, step):
             assert rel_l2(du[big], dr[big]) < 2e-2, n
             moved += float(dr[big].abs().sum())
     assert moved > 0
+
+
+def test_activation_checkpointing_matches(gpu):
+    """`use_checkpoint` (True in every GCD config): ResBlocks and transformers re-run on HIP kernels during
+    the backward pass — same gradients, less memory held between forward and backward."""
+    from gcd_amd import training as TR
+    net, sd = _tiny_unet(gpu, salt=5)
+    T, H, W = 4, 16, 16
+    cfg = O.TINY
+    g = _gen(21)
+    x = torch.randn(2 * T, 8, H, W, generator=g).to(gpu)
+    ts = torch.linspace(-1.0, 1.5, 2 * T).to(gpu)
+    ctx = torch.randn(2 * T, 1, cfg.context_dim, generator=g).to(gpu)
+    y = torch.randn(2 * T, cfg.adm_in_channels + cfg.aux_emb_dim, generator=g).clamp(-1, 1).to(gpu)
+    ioi = torch.zeros(2, T, device=gpu)
+    tgt = torch.randn(2 * T, 4, H, W, generator=g).to(gpu)
+    grads, held = [], []
+    for ck in (False, True):
+        for p in net.parameters():
+            p.grad = None
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        out = TR.unet_forward_train(net, x, ts, ctx, y, T, ioi, use_checkpoint=ck)
+        torch.cuda.synchronize()
+        held.append(torch.cuda.memory_allocated() - base)
+        ((out - tgt) ** 2).mean().backward()
+        torch.cuda.synchronize()
+        grads.append({n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 1000
+    for n in grads[0]:      # (bias / norm-parameter gradients are sums of atomics: equal up to summation order)
+        assert rel_l2(grads[1][n], grads[0][n]) < 1e-5, n
+    print(f"activations held after forward: {held[0] / 2**20:.0f} MiB plain, {held[1] / 2**20:.0f} MiB checkpointed")
+    assert held[1] < 0.5 * held[0]
