@@ -42,6 +42,7 @@ class GemmDesc(C.Structure):
         ("ld_ln_sum", C.c_int64),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("asym_pad", C.c_int32),
         ("colstats", C.c_void_p), ("out_blocked", C.c_int32), ("a_blocked", C.c_int32),
+        ("operand_bf16", C.c_int32),
     ]
 
 
@@ -88,6 +89,8 @@ SIGNATURES = {
     "gcd_softmax_bwd_rows": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _f, _vp]),
     "gcd_attn_temporal_bwd": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
     "gcd_cast_scale_f32_f16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _f, _vp]),
+    "gcd_cast_f32_bf16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),
+    "gcd_cast_f16_bf16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),
     "gcd_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "gcd_graph_begin_capture": (_i, [_vp]),
     "gcd_graph_end_capture": (_i, [_vp, C.POINTER(_vp)]),

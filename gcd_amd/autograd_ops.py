@@ -21,6 +21,7 @@ tests/test_backward_gpu.py); it is unfused and is not the measured inference pat
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -30,6 +31,20 @@ from ._lib import GEMM_CONV3X3, GEMM_PLAIN, GEMM_TEMPORAL3, OUT_F16, OUT_F32, ch
 
 _f32 = torch.float32
 _f16 = torch.float16
+_bf16 = torch.bfloat16
+
+# Operand type of the BACKWARD contractions (dX = dY W, dW = dY^T X): "fp16" (default; incoming gradients
+# are rounded to fp16, the caller applies a static loss scale so that small values survive) or "bf16"
+# (gcd_gemm_desc.operand_bf16 on the general GEMM kernel: fp32's exponent range, no loss scale needed,
+# 8 significant bits).  The forward pass is fp16 either way.  Set through `set_grad_dtype`.
+GRAD_DTYPE = os.environ.get("GCD_TRAIN_GRAD_DTYPE", "fp16")
+
+
+def set_grad_dtype(name: str) -> None:
+    global GRAD_DTYPE
+    if name not in ("fp16", "bf16"):
+        raise ValueError("grad dtype must be 'fp16' or 'bf16'")
+    GRAD_DTYPE = name
 
 
 def _stream():
@@ -57,15 +72,53 @@ def _cast16_into(x32: torch.Tensor, y16: torch.Tensor) -> None:
         y16.copy_(x32)
 
 
-def _t16_padded(x16: torch.Tensor) -> torch.Tensor:
-    """[R, C] fp16 -> [C, Rp] fp16 with Rp = R rounded up to 32 and zero padding (a GEMM operand whose
-    contraction axis is the token axis)."""
+def _t16_padded(x16: torch.Tensor, granule: int = 32) -> torch.Tensor:
+    """[R, C] fp16 / bf16 -> [C, Rp] with Rp = R rounded up to the GEMM's K granule and zero padding (a
+    GEMM operand whose contraction axis is the token axis)."""
     R, Cc = x16.shape
-    Rp = (R + 31) // 32 * 32
-    out = torch.zeros(Cc, Rp, dtype=_f16, device=x16.device) if Rp != R else \
-        torch.empty(Cc, Rp, dtype=_f16, device=x16.device)
+    Rp = (R + granule - 1) // granule * granule
+    out = torch.zeros(Cc, Rp, dtype=x16.dtype, device=x16.device) if Rp != R else \
+        torch.empty(Cc, Rp, dtype=x16.dtype, device=x16.device)
     ops.transpose_f16(x16, out[:, :R])
     return out
+
+
+def _to_bf16(x: torch.Tensor) -> torch.Tensor:
+    y = torch.empty(x.shape, dtype=_bf16, device=x.device)
+    ops.cast_bf16(x, y)
+    return y
+
+
+def _grad_contractions(dy32: torch.Tensor, x16: torch.Tensor, w_t16: torch.Tensor, need_dx: bool,
+                       need_dw: bool):
+    """The two contractions every Linear-shaped backward needs, on gcd_gemm_f16:
+         dX [M, K] = dY [M, N] @ W [N, K]      (w_t16 = W^T, [K, N], fp16)
+         dW [N, K] = dY^T [N, M] @ X [M, K]    (x16 fp16 [M, K])
+    in fp16 (default) or bf16 operands (GRAD_DTYPE; bf16 needs 64-deep contraction axes, else fp16)."""
+    M, N = dy32.shape
+    K = w_t16.shape[0]
+    dev = dy32.device
+    bf = GRAD_DTYPE == "bf16" and N % 64 == 0
+    dy16 = _to_bf16(dy32) if bf else _cast16(dy32)
+    dx = dw = None
+    if need_dx:
+        dx = torch.empty(M, K, dtype=_f32, device=dev)
+        wt = w_t16.to(_bf16) if bf else w_t16
+        if N % 32 == 0:
+            ops.gemm(dy16, wt, dx, M=M, operand_bf16=bf)
+        else:   # N a multiple of 16 only (the padded last conv): widen the contraction axis with zeros
+            Np = (N + 31) // 32 * 32
+            dyp = torch.zeros(M, Np, dtype=_f16, device=dev)
+            dyp[:, :N] = dy16
+            wtp = torch.zeros(K, Np, dtype=_f16, device=dev)
+            wtp[:, :N] = wt
+            ops.gemm(dyp, wtp, dx, M=M)
+    if need_dw:
+        dw = torch.empty(N, K, dtype=_f32, device=dev)
+        g = 64 if bf else 32
+        xs = _to_bf16(x16) if bf else x16
+        ops.gemm(_t16_padded(dy16, g), _t16_padded(xs, g), dw, M=N, operand_bf16=bf)
+    return dx, dw
 
 
 def _colsum(x32: torch.Tensor, rows_per_block: Optional[int] = None) -> torch.Tensor:
@@ -129,23 +182,9 @@ class Linear16(torch.autograd.Function):
         M, K = x16.shape
         N = weight.shape[0]
         dy = dy.contiguous()
-        dy16 = _cast16(dy)
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            wt16 = PACK.get(weight, "lin_t", lambda w: w.t().contiguous().to(_f16))     # [K, N]
-            dx = torch.empty(M, K, dtype=_f32, device=dy.device)
-            if N % 32 == 0:
-                ops.gemm(dy16, wt16, dx, M=M)
-            else:   # N a multiple of 16 only (padded last conv ...): widen the contraction axis with zeros
-                Np = (N + 31) // 32 * 32
-                dyp = torch.zeros(M, Np, dtype=_f16, device=dy.device)
-                dyp[:, :N] = dy16
-                wtp = torch.zeros(K, Np, dtype=_f16, device=dy.device)
-                wtp[:, :N] = wt16
-                ops.gemm(dyp, wtp, dx, M=M)
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty(N, K, dtype=_f32, device=dy.device)
-            ops.gemm(_t16_padded(dy16), _t16_padded(x16), dw, M=N)       # dY^T [N, Mp] @ (X^T [K, Mp])^T
+        db = None
+        wt16 = PACK.get(weight, "lin_t", lambda w: w.t().contiguous().to(_f16))     # [K, N]
+        dx, dw = _grad_contractions(dy, x16, wt16, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dy)[0]
         return dx, dw, db
@@ -198,31 +237,31 @@ class Conv3x3(torch.autograd.Function):
         Mout = frames * geo["Ho"] * geo["Wo"]
         Min = frames * geo["Hi"] * geo["Wi"]
         dev = dy.device
-        dy16 = torch.zeros(Mout, cout_p, dtype=_f16, device=dev) if cout_p != Cout else None
-        if dy16 is None:
-            dy16 = _cast16(dy.contiguous())
-        else:
-            _cast16_into(dy.contiguous(), dy16[:, :Cout])
+        dyp = dy.contiguous()
+        if cout_p != Cout:
+            dyp = torch.zeros(Mout, cout_p, dtype=_f32, device=dev)
+            dyp[:, :Cout] = dy
         lib = _lib.load()
         w16 = PACK.get(weight, f"c3_{cin_p}_{cout_p}",
                        lambda w: packing.pack_conv3x3(w, cin_pad=cin_p, cout_pad=cout_p))     # [cout_p, 9*cin_p]
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            wt16 = PACK.get(weight, f"c3t_{cin_p}_{cout_p}", lambda w: w16.t().contiguous())   # [9*cin_p, cout_p]
-            dcol = torch.empty(Mout, 9 * cin_p, dtype=_f32, device=dev)
-            ops.gemm(dy16, wt16, dcol, M=Mout)
-            dxp = torch.empty(Min, cin_p, dtype=_f32, device=dev)
-            check(lib.gcd_col2im3x3_f32(dcol.data_ptr(), dxp.data_ptr(), cin_p, frames, cin_p, geo["Hi"],
-                                        geo["Wi"], geo["Ho"], geo["Wo"], geo["stride"], geo["upsample"], 0,
-                                        _stream()), "gcd_col2im3x3_f32")
-            dx = dxp[:, :Cin] if cin_p != Cin else dxp
+        wt16 = PACK.get(weight, f"c3t_{cin_p}_{cout_p}", lambda w: w16.t().contiguous())      # [9*cin_p, cout_p]
+        col = None
         if ctx.needs_input_grad[1]:
             col = torch.empty(Mout, 9 * cin_p, dtype=_f16, device=dev)
             check(lib.gcd_im2col3x3_f16(x16.data_ptr(), _ld(x16), col.data_ptr(), frames, cin_p, geo["Hi"],
                                         geo["Wi"], geo["Ho"], geo["Wo"], geo["stride"], geo["upsample"], 0,
                                         _stream()), "gcd_im2col3x3_f16")
-            dwp = torch.empty(cout_p, 9 * cin_p, dtype=_f32, device=dev)
-            ops.gemm(_t16_padded(dy16), _t16_padded(col), dwp, M=cout_p)
+        # the convolution as a Linear over im2col rows: dcol = dY W, dW = dY^T col
+        dcol, dwp = _grad_contractions(dyp, col if col is not None else x16[:, :0], wt16,
+                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dx = dw = db = None
+        if dcol is not None:
+            dxp = torch.empty(Min, cin_p, dtype=_f32, device=dev)
+            check(lib.gcd_col2im3x3_f32(dcol.data_ptr(), dxp.data_ptr(), cin_p, frames, cin_p, geo["Hi"],
+                                        geo["Wi"], geo["Ho"], geo["Wo"], geo["stride"], geo["upsample"], 0,
+                                        _stream()), "gcd_col2im3x3_f32")
+            dx = dxp[:, :Cin] if cin_p != Cin else dxp
+        if dwp is not None:
             dw = dwp.reshape(cout_p, 3, 3, cin_p).permute(0, 3, 1, 2)[:Cout, :Cin].contiguous()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dy.contiguous())[0]
@@ -260,23 +299,22 @@ class ConvT3(torch.autograd.Function):
         Cout = weight.shape[0]
         dev = dy.device
         dy = dy.contiguous()
-        dy16 = _cast16(dy)
         lib = _lib.load()
         w16 = PACK.get(weight, "t3", packing.pack_conv_t3)
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            wt16 = PACK.get(weight, "t3t", lambda w: w16.t().contiguous())        # [3C, Cout]
-            dcol = torch.empty(M, 3 * Cc, dtype=_f32, device=dev)
-            ops.gemm(dy16, wt16, dcol, M=M)
-            dx = torch.empty(M, Cc, dtype=_f32, device=dev)
-            check(lib.gcd_col2im_t3_f32(dcol.data_ptr(), dx.data_ptr(), Cc, M, Cc, ctx.T, ctx.HW, _stream()),
-                  "gcd_col2im_t3_f32")
+        wt16 = PACK.get(weight, "t3t", lambda w: w16.t().contiguous())            # [3C, Cout]
+        col = None
         if ctx.needs_input_grad[1]:
             col = torch.empty(M, 3 * Cc, dtype=_f16, device=dev)
             check(lib.gcd_im2col_t3_f16(x16.data_ptr(), _ld(x16), col.data_ptr(), M, Cc, ctx.T, ctx.HW, _stream()),
                   "gcd_im2col_t3_f16")
-            dwp = torch.empty(Cout, 3 * Cc, dtype=_f32, device=dev)
-            ops.gemm(_t16_padded(dy16), _t16_padded(col), dwp, M=Cout)
+        dcol, dwp = _grad_contractions(dy, col if col is not None else x16[:, :0], wt16,
+                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dx = dw = db = None
+        if dcol is not None:
+            dx = torch.empty(M, Cc, dtype=_f32, device=dev)
+            check(lib.gcd_col2im_t3_f32(dcol.data_ptr(), dx.data_ptr(), Cc, M, Cc, ctx.T, ctx.HW, _stream()),
+                  "gcd_col2im_t3_f32")
+        if dwp is not None:
             dw = dwp.reshape(Cout, 3, Cc).permute(0, 2, 1).reshape(Cout, Cc, 3, 1, 1).contiguous()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dy)[0]

@@ -526,6 +526,30 @@ __global__ __launch_bounds__(256) void cast_scale_kernel(const float* __restrict
   }
 }
 
+// fp32 / fp16 -> bfloat16, round to nearest even (NaN kept quiet)
+__device__ __forceinline__ unsigned short bf16_rne(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const T* __restrict__ x, int64_t ldx,
+                                                        unsigned short* __restrict__ y, int64_t ldy, int64_t M,
+                                                        int C) {
+  const int cv = C >> 2;
+  const int64_t total = M * cv;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t m = idx / cv;
+    const int c = (int)(idx - m * cv) * 4;
+    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+    us4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = bf16_rne((float)x[m * ldx + c + e]);
+    *(us4*)(y + m * ldy + c) = o;
+  }
+}
+
 // torch.optim.Adam (no amsgrad; L2 weight decay added to the gradient), one fused pass
 // (diffusion.py:412-431 instantiates the optimizer the config names — Adam, lr 2e-5 for GCD).
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -712,6 +736,24 @@ extern "C" int gcd_cast_scale_f32_f16(const float* x, int64_t ldx, void* y16, in
   GCD_CHECK_ARG(x && y16 && M > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "gcd_cast_scale_f32_f16: bad args");
   hipLaunchKernelGGL(cast_scale_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx,
                      (f16*)y16, ldy, M, C, scale);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gcd_cast_f32_bf16(const float* x, int64_t ldx, void* y16, int64_t ldy, int64_t M, int C,
+                                 void* stream) {
+  GCD_CHECK_ARG(x && y16 && M > 0 && C > 0 && C % 4 == 0 && ldy % 4 == 0, "gcd_cast_f32_bf16: bad args");
+  hipLaunchKernelGGL(cast_bf16_kernel<float>, dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, x,
+                     ldx, (unsigned short*)y16, ldy, M, C);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gcd_cast_f16_bf16(const void* x16, int64_t ldx, void* y16, int64_t ldy, int64_t M, int C,
+                                 void* stream) {
+  GCD_CHECK_ARG(x16 && y16 && M > 0 && C > 0 && C % 4 == 0 && ldy % 4 == 0, "gcd_cast_f16_bf16: bad args");
+  hipLaunchKernelGGL(cast_bf16_kernel<f16>, dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                     (const f16*)x16, ldx, (unsigned short*)y16, ldy, M, C);
   GCD_CHECK_LAUNCH();
   return 0;
 }

@@ -26,7 +26,13 @@
 #include "gemm_common.h"
 
 
-template <int BM, int BN, int WM, int WN, int MODE>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// BF16: the two operands are bfloat16 instead of fp16 (gcd_gemm_desc.operand_bf16; PLAIN mode, fp32
+// output): the same 16-bit staging, swizzle and fragment reads, v_mfma_f32_16x16x32_bf16 instead of
+// ..._f16 — same shape, same rate on gfx950; bf16 buys exponent range (gradients without loss scaling),
+// not speed, and costs 3 mantissa bits.
+template <int BM, int BN, int WM, int WN, int MODE, bool BF16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmK p) {
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int WAVES_N = BN / WN;
@@ -170,7 +176,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmK p) {
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+          if constexpr (BF16)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i]),
+                                                                __builtin_bit_cast(bf16x8, af[j]), acc[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
     }
   }
 
@@ -265,11 +275,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmK p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE, bool BF16 = false>
 static int launch_gemm(const GemmK& k, hipStream_t s) {
   constexpr int smem = 2 * (BM + BN) * 128;
   static GcdPerDeviceOnce attr_once;
-  auto fn = gemm_f16_kernel<BM, BN, WM, WN, MODE>;
+  auto fn = gemm_f16_kernel<BM, BN, WM, WN, MODE, BF16>;
   if (attr_once.first_use()) {
     GCD_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       smem));
@@ -297,6 +307,14 @@ static int dispatch_tile(const GemmK& k, hipStream_t s) {
   // workgroups so that two are resident per CU
   const int64_t tiles128 = (int64_t)((k.M + 127) / 128) * ((k.N + 159) / 160);
   const int impl = gcd_tune_get(GCD_TUNE_GEMM_IMPL);
+  if constexpr (MODE == GCD_GEMM_PLAIN) {
+    if (k.operand_bf16) {   // validated by gcd_gemm_f16: PLAIN mode, fp32 output
+      if (use160 && ((tiles128 <= 320 && impl != 5) || impl == 6))
+        return launch_gemm<64, 160, 32, 80, MODE, true>(k, s);
+      if (use160) return launch_gemm<128, 160, 64, 80, MODE, true>(k, s);
+      return launch_gemm<128, 128, 64, 64, MODE, true>(k, s);
+    }
+  }
   if (use160 && ((tiles128 <= 320 && impl != 5) || impl == 6)) return launch_gemm<64, 160, 32, 80, MODE>(k, s);
   if (use160) return launch_gemm<128, 160, 64, 80, MODE>(k, s);
   return launch_gemm<128, 128, 64, 64, MODE>(k, s);
@@ -430,6 +448,7 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
   k.colstats = d->colstats;
   k.out_blocked = d->out_blocked ? 1 : 0;
   k.a_blocked = d->a_blocked ? 1 : 0;
+  k.operand_bf16 = d->operand_bf16 ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
 
   // kernel choice: the 256 x 320 ping-pong kernel whenever the grid fills most of the chip with
@@ -442,6 +461,13 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
     // K (or the channels per tap) a multiple of 32 but not of 64: only the ping-pong kernel's 32-deep
     // sub-tiles can walk it
     if (d->K % 64 != 0 || (d->mode != GCD_GEMM_PLAIN && d->Cin % 64 != 0)) use_pp = true;
+  }
+  if (d->operand_bf16) {
+    GCD_CHECK_ARG(d->mode == GCD_GEMM_PLAIN && d->out_kind == GCD_OUT_F32 && d->K % 64 == 0 && !d->ln_out16 &&
+                      !d->colstats && !d->out_blocked && !d->a_blocked,
+                  "gcd_gemm_f16: bf16 operands are implemented for PLAIN mode with fp32 output and "
+                  "K %% 64 == 0 (K=%d), without fused LayerNorm / colstats / blocked layouts", d->K);
+    use_pp = false;          // the general 128-row kernel carries the bf16 instantiations
   }
   if (d->ln_out16) {
     GCD_CHECK_ARG(use_pp && d->N == 320 && d->out_kind == GCD_OUT_F32 && d->ln_gamma && d->ln_beta &&
@@ -477,7 +503,8 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
   if (const int rc = validate_geometry(d)) return rc;
 
   // split-K: few 256x320 tiles (<= 96 of 256 CUs) and a long K — the 3x3 convs of the 9x16 level
-  if (d->workspace && !d->ln_out16 && !d->colstats && !d->a_blocked && d->out_kind != GCD_OUT_GEGLU &&
+  if (d->workspace && !d->ln_out16 && !d->colstats && !d->a_blocked && !d->operand_bf16 &&
+      d->out_kind != GCD_OUT_GEGLU &&
       (impl == 0 || impl == 7) &&
       gcd_gemm_pp_supported(k, d->mode) && d->N >= 160 && d->N % 4 == 0) {
     const int64_t tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 319) / 320);

@@ -45,6 +45,7 @@ struct GemmK {
   // (gcd_gemm_desc.colstats): [2 * M / 64, N]
   float* colstats;
   int out_blocked, a_blocked;   // tile-blocked GEGLU hidden tensor (gcd_gemm_desc.out_blocked / a_blocked)
+  int operand_bf16;             // A and W are bfloat16 (general kernel, PLAIN mode, fp32 output)
 };
 
 // gemm_pp.hip: the 256 x 320 ping-pong kernel.

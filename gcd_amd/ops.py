@@ -121,7 +121,7 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mod
          s_acc: float = 1.0, s_r1: float = 1.0, s_r2: float = 1.0, frame_alpha=None,
          rows_per_alpha: int = 1, r1_blend: bool = False, conv=None,
          alg_flops_scale: float = 1.0, ln=None, colstats=None, probe_colstats: bool = False,
-         out_blocked: bool = False, a_blocked: bool = False):
+         out_blocked: bool = False, a_blocked: bool = False, operand_bf16: bool = False):
     """out = epilogue(A @ W^T); see gcd_gemm_desc in include/gcd_amd.h.
 
     conv: dict(Cin, Hi, Wi, Ho, Wo, stride, upsample) for GEMM_CONV3X3 or dict(Cin, T, HW) for
@@ -131,7 +131,8 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mod
     probe_colstats: do not launch; return whether `colstats` would be honoured for this call.
     """
     _need_gpu(a16, w16, out)
-    assert a16.dtype == torch.float16 and w16.dtype == torch.float16
+    want = torch.bfloat16 if operand_bf16 else torch.float16
+    assert a16.dtype == want and w16.dtype == want, f"operands must be {want}"
     N, K = w16.shape
     d = GemmDesc()
     d.A, d.W, d.out = a16.data_ptr(), w16.data_ptr(), out.data_ptr()
@@ -156,7 +157,7 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mod
     if frame_alpha is not None:
         d.frame_alpha, d.rows_per_alpha, d.r1_blend = frame_alpha.data_ptr(), rows_per_alpha, int(r1_blend)
     d.out_kind = out_kind
-    d.out_blocked, d.a_blocked = int(out_blocked), int(a_blocked)
+    d.out_blocked, d.a_blocked, d.operand_bf16 = int(out_blocked), int(a_blocked), int(operand_bf16)
     if ln is not None:
         # fused LayerNorm of the output rows: dict(gamma, beta, out16[, eps, addvec, rows_per_vec, sum_out])
         _need_gpu(ln["gamma"], ln["beta"], ln["out16"], ln.get("addvec"), ln.get("sum_out"))
@@ -358,6 +359,17 @@ def unpack_output(tok32, out_nchw, Cout: int, N: int, HW: int):
     check(_lib.load().gcd_unpack_output(tok32.data_ptr(), _ld(tok32), out_nchw.data_ptr(), Cout, N,
                                         HW, _stream()), "gcd_unpack_output")
     return out_nchw
+
+
+def cast_bf16(x, y16):
+    """fp32 or fp16 [M, C] -> bfloat16 (round to nearest even), for `gemm(..., operand_bf16=True)`."""
+    _need_gpu(x, y16)
+    M, Cc = x.shape
+    assert y16.dtype == torch.bfloat16
+    fn = _lib.load().gcd_cast_f32_bf16 if x.dtype == torch.float32 else _lib.load().gcd_cast_f16_bf16
+    assert x.dtype in (torch.float32, torch.float16)
+    check(fn(x.data_ptr(), _ld(x), y16.data_ptr(), _ld(y16), M, Cc, _stream()), "gcd_cast_*_bf16")
+    return y16
 
 
 def cast_f16(x32, y16):

@@ -142,6 +142,11 @@ typedef struct gcd_gemm_desc {
      (gcd_gemm_hidden_blocked_supported).                                                           */
   int32_t out_blocked;
   int32_t a_blocked;
+  /* 1: A and W hold bfloat16 instead of fp16 (GCD_GEMM_PLAIN, fp32 output, K % 64 == 0; runs on the
+     general 128-row kernel with v_mfma_f32_16x16x32_bf16).  Same MFMA rate as fp16 on gfx950: the point
+     is exponent range — the fine-tune step's gradient GEMMs without loss scaling — at 8 instead of 11
+     significant bits (7x over the 1e-3 inference tolerance, so inference stays fp16). */
+  int32_t operand_bf16;
 } gcd_gemm_desc;
 
 /* Replaces torch.nn.Linear / Conv2d / Conv3d forward on the hot path:
@@ -318,6 +323,9 @@ int gcd_attn_temporal_bwd(const void* qkv16, int64_t ld, const float* dO, int64_
                           int64_t lddq, int clips, int T, int HW, int heads, void* stream);
 /* y16 = fp16(x * scale): gradients enter the fp16 GEMMs pre-scaled (loss scaling), the GEMM's s_acc
  * removes the factor in fp32.                                                                        */
+/* y = bfloat16(x) (round to nearest even), for operand_bf16 GEMMs; x fp32 or (the _f16 form) fp16.      */
+int gcd_cast_f32_bf16(const float* x, int64_t ldx, void* y16, int64_t ldy, int64_t M, int C, void* stream);
+int gcd_cast_f16_bf16(const void* x16, int64_t ldx, void* y16, int64_t ldy, int64_t M, int C, void* stream);
 int gcd_cast_scale_f32_f16(const float* x, int64_t ldx, void* y16, int64_t ldy, int64_t M, int C,
                            float scale, void* stream);
 /* torch.optim.Adam step (no amsgrad; weight_decay added to the gradient), in place; grad_scale is

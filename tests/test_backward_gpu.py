@@ -420,3 +420,58 @@ def test_activation_checkpointing_matches(gpu):
         assert rel_l2(grads[1][n], grads[0][n]) < 1e-5, n
     print(f"activations held after forward: {held[0] / 2**20:.0f} MiB plain, {held[1] / 2**20:.0f} MiB checkpointed")
     assert held[1] < 0.5 * held[0]
+
+
+def test_bf16_gradient_contractions(gpu):
+    """`set_grad_dtype("bf16")`: the backward contractions on bfloat16 operands (fp32's exponent range: no
+    loss scale; 8 significant bits) — operator gradients and one VideoResBlock against torch.autograd.
+    Unscaled gradients of 1e-6 magnitude, which fp16 would flush, must come through."""
+    from gcd_amd import autograd_ops as A
+    from gcd_amd import training as TR
+    A.set_grad_dtype("bf16")
+    try:
+        g = _gen(31)
+        M, K, N = 500, 320, 128
+        x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+        dy = torch.randn(M, N, generator=g) * 1e-6                    # far below fp16's normal range
+        xr, wr, br = _leaf(x), _leaf(w), _leaf(b)
+        F.linear(xr, wr, br).backward(dy)
+        xg, wg, bg = _leaf(x, gpu), _leaf(w, gpu), _leaf(b, gpu)
+        A.linear(xg, wg, bg).backward(dy.to(gpu))
+        print("Linear, bf16 gradient operands, |dy| ~ 1e-6:")
+        _check("dx", xg.grad, xr.grad, 1e-2)
+        _check("dw", wg.grad, wr.grad, 1e-2)
+        frames, H, W, C = 2, 8, 8, 64
+        x = torch.randn(frames, C, H, W, generator=g)
+        w = torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C)
+        xr, wr = _leaf(x), _leaf(w)
+        yr = F.conv2d(xr, wr, None, padding=1)
+        dy = torch.randn(yr.shape, generator=g)
+        yr.backward(dy)
+        xg, wg = _leaf(_tok(x), gpu), _leaf(w, gpu)
+        A.conv3x3(xg, wg, None, frames, H, W).backward(_tok(dy).to(gpu))
+        print("Conv3x3, bf16 gradient operands:")
+        _check("dx", xg.grad, _tok(xr.grad), 1e-2)
+        _check("dw", wg.grad, wr.grad, 1e-2)
+        # one VideoResBlock of the TINY UNet
+        net, sd = _tiny_unet(gpu)
+        T = 4
+        x = torch.randn(2 * T, 64, 8, 8, generator=g)
+        emb = torch.randn(2 * T, 256, generator=g)
+        ioi = torch.zeros(2, T)
+        p = "input_blocks.1.0"
+        sdr = {k: _leaf(v) for k, v in sd.items() if k.startswith(p)}
+        xr, er = _leaf(x), _leaf(emb)
+        yr = O._video_resblock(sdr, p, xr, er, T, ioi)
+        dy = torch.randn(yr.shape, generator=g)
+        yr.backward(dy)
+        rb = net.input_blocks[1][0]
+        xg, eg = _leaf(_tok(x), gpu), _leaf(emb, gpu)
+        TR._video_resblock(rb, xg, eg, 2 * T, T, 8, 8, ioi.to(gpu)).backward(_tok(dy).to(gpu))
+        print("VideoResBlock, bf16 gradient operands:")
+        _check("dx", _untok(xg.grad, 2 * T, 8, 8), xr.grad, 1.5e-2)
+        worst = max(rel_l2(prm.grad, sdr[f"{p}.{n}"].grad) for n, prm in rb.named_parameters() if prm.numel() > 1)
+        print(f"  worst parameter gradient rel-L2 {worst:.2e}")
+        assert worst < 1.5e-2
+    finally:
+        A.set_grad_dtype("fp16")

@@ -465,6 +465,34 @@ def test_groupnorm(gpu, frames, HW, C1, C2, per_clip_T):
     assert rel_l2(raw.float(), tok) < TOL_F16
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (1000, 64, 640), (4032, 1280, 1280), (77, 48, 64)])
+def test_gemm_bf16_operands(gpu, M, N, K):
+    """gcd_gemm_desc.operand_bf16: bfloat16 A and W on the general kernel (v_mfma_f32_16x16x32_bf16), fp32
+    output with bias and residual — against fp32 math on the same bf16-rounded operands; the cast kernels
+    against torch's round-to-nearest-even; unsupported combinations are refused."""
+    from gcd_amd import ops
+    g = _gen(51)
+    a32, w32 = torch.randn(M, K, generator=g) * 3, torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias, r1 = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    a = torch.empty(M, K, dtype=torch.bfloat16, device=gpu)
+    ops.cast_bf16(a32.to(gpu), a)
+    assert torch.equal(a.cpu(), a32.to(torch.bfloat16)), "gcd_cast_f32_bf16 is not round-to-nearest-even"
+    w = torch.empty(N, K, dtype=torch.bfloat16, device=gpu)
+    ops.cast_bf16(w32.half().to(gpu), w)                     # the fp16 -> bf16 form
+    assert torch.equal(w.cpu(), w32.half().to(torch.bfloat16))
+    ref = a.cpu().float() @ w.cpu().float().t() + bias + r1
+    out = torch.empty(M, N, device=gpu)
+    ops.gemm(a, w, out, M=M, bias=bias.to(gpu), r1=r1.to(gpu), operand_bf16=True)
+    torch.cuda.synchronize()
+    e = rel_l2(out, ref)
+    assert e < TOL_F32, f"bf16 GEMM M={M} N={N} K={K}: rel-L2 {e:.3e}"
+    with pytest.raises(Exception, match="bf16"):
+        ops.gemm(a, w, torch.empty(M, N, device=gpu, dtype=torch.float16), M=M, out_kind=ops.OUT_F16,
+                 operand_bf16=True)
+    with pytest.raises(AssertionError):
+        ops.gemm(a.to(torch.float16), w, out, M=M, operand_bf16=True)
+
+
 def _colsum_ref(out, rows=64):
     b = out.double().reshape(out.shape[0] // rows, rows, out.shape[1])
     return torch.stack([b.sum(1), (b * b).sum(1)], 1).reshape(-1, out.shape[1])   # [2 * blocks, N]
