@@ -534,6 +534,342 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const f16* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Spatial flash attention, 64 queries per wave, SOFTWARE-PIPELINED (the product kernel for S >= 1024).
+//
+// What gfx950 overlaps (tools/issue_probe.cpp, profiles/r02k_issue_probe.txt; cycles per instruction of
+// a wave64: MFMA 32x32x16 f16 32, v_exp_f32 8-9, plain VALU 4-5):
+//   * a wave's OWN plain VALU / transcendental instructions issue in the shadow of its MFMA: 16 x {MFMA,
+//     exp, exp} costs what 16 MFMAs cost, {MFMA, cvt, add, add, exp, exp} 33 cycles per group;
+//   * ANOTHER wave's do not while the MFMA wave issues MFMAs back to back: an MFMA stream next to an
+//     exp / fma / cvt stream on the same SIMD costs (nearly) the sum of the two;
+//   * v_dot2(c)_f32_f16 and v_pk_*_f32 do not run under an MFMA at all (+18 cycles per group each).
+// attn_spatial64_kernel above issues each wave's work as  S^T MFMAs | softmax VALU | P V MFMAs: by the
+// rules above nothing overlaps inside a wave and little between the two waves of a SIMD (which belong to
+// different workgroups): 2315 SIMD cycles per wave and tile for 1152 of MFMA + ~1400 of softmax — the
+// serial sum.  Here the 18 MFMAs a softmax pass can cover are issued INSIDE it, one per two v_exp_f32:
+//     softmax(block 0, tile kt)  covers  P V (block 1, tile kt-1)  +  S^T (block 1, tile kt)
+//     softmax(block 1, tile kt)  covers  P V (block 0, tile kt)    +  S^T (block 0, tile kt+1)
+// and the denominator is summed from the fp32 exponentials with v_add_f32 (two chains) instead of
+// v_dot2 over the packed fp16 values (so it differs from the kernel above by the fp16 rounding of P:
+// <= 2^-12 relative, unbiased).  The K and V^T fragments are read from LDS once per query block
+// instead of once per tile (their registers are live for half a pass each), the ring has four stages and
+// the barrier sits between the two passes (tile kt+1's K is needed from the second one on); the rare
+// "reference moved" path is ONE branch laid out as unlikely — a taken branch costs a wave hundreds of
+// cycles of instruction fetch (two taken branches per pass were 27 % of a lone wave's time).
+// Measured (tools/attn_bench, same box): 72x128 tokens 3187 -> 3068 us, 36x64 495 -> 465 us; SQ counters
+// of the new kernel: VALU issue 37 % of wave cycles (x 2 waves = 73 % of the SIMD), MFMA busy 51 %, 27 %
+// parked on s_waitcnt / s_barrier.  The 64 v_exp_f32 per wave and tile (16 VALU-port cycles each by the
+// SQ's accounting) are 60 % of that VALU time: the kernel is transcendental-bound, not matrix-bound.
+// ------------------------------------------------------------------------------------------------
+template <bool PRESCALED>
+__global__ __launch_bounds__(256, 2) void attn_spatial64p_kernel(const f16* __restrict__ qkv, int64_t ld,
+                                                                 const f16* __restrict__ vt, int S_pad,
+                                                                 f16* __restrict__ out, int64_t ldo,
+                                                                 int S, int heads, int nqb,
+                                                                 float c /* scale * log2(e) */) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * 16384];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  int qb, head, frame;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    qb = L % nqb;
+    const int fh = L / nqb;
+    head = fh % heads;
+    frame = fh / heads;
+  }
+  const int C = heads * 64;
+  const int q0 = qb * 256 + wave * 64;
+
+  f16x8 qf[2][4];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    int qi = q0 + 32 * b + l31;
+    qi = qi < S ? qi : S - 1;
+    const f16* qp = qkv + ((int64_t)frame * S + qi) * ld + head * 64 + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[b][ks] = *(const f16x8*)(qp + ks * 16);
+  }
+  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  f16x8 kones = zero8;
+  if (half == 0) kones[0] = (f16)1.f;
+  f16x8 qm[2] = {zero8, zero8};
+  float mref[2] = {0.f, 0.f};
+  float lsum[2] = {0.f, 0.f};
+
+  const int prow = t >> 3;
+  const int cl = (t & 7) ^ ((prow >> 1) & 7);
+  const f16* kbase = qkv + (int64_t)frame * S * ld + C + head * 64 + cl * 8;
+  const f16* vbase = vt + (((int64_t)frame * heads + head) * 64) * S_pad + cl * 8;
+  const int ntiles = (S + 63) >> 6;
+  auto stage = [&](int kt) {
+    if (kt < ntiles) {
+      const int kv0 = kt << 6;
+      char* Ks = smem + (kt & 3) * 16384;
+      char* Vs = Ks + 8192;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = prow + 32 * i;
+        int key = kv0 + row;
+        key = key < S ? key : S - 1;
+        glds16(kbase + (int64_t)key * ld, Ks + (i * 256 + wave * 64) * 16);
+        glds16(vbase + (int64_t)row * S_pad + kv0, Vs + (i * 256 + wave * 64) * 16);
+      }
+    }
+  };
+
+  f32x16 o0[2], o1[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[b][r] = o1[b][r] = 0.f;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int foff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) foff[ks] = lds_tile_off(l31, 2 * ks + half);
+
+  f32x16 sc[2][2];   // [query block][key half]: S^T - m_ref of the tile the block works on
+  f16x8 pfb[2][4];   // P^T fragments (B operand) per query block; zero = "no tile yet" for the first P V
+  f16x8 vf[8];       // V^T fragments of the tile whose P V products are being issued
+  f16x8 kf[2][4];    // K fragments of the tile whose S^T products are being issued
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pfb[0][i] = pfb[1][i] = zero8;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) vf[i] = zero8;
+
+  auto load_k = [&](int kt) {
+    const int sbase = (kt & 3) * 16384;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kf[kb][ks] = *(const f16x8*)(smem + foff[ks] + sbase + 4096 * kb);
+  };
+  auto load_v = [&](int kt) {
+    const int sbase = (kt & 3) * 16384 + 8192;
+#pragma unroll
+    for (int c2 = 0; c2 < 4; ++c2) {
+      vf[2 * c2] = *(const f16x8*)(smem + foff[c2] + sbase);
+      vf[2 * c2 + 1] = *(const f16x8*)(smem + foff[c2] + sbase + 4096);
+    }
+  };
+  // MFMA i (0..9) of S^T - m_ref for query block b: the two key halves alternate (dependent MFMAs are
+  // two issues apart); step 0 of a half is the reference-max k-step
+  auto s_mfma = [&](const int b, const int i) {
+    const int kb = i & 1, st = i >> 1;
+    if (st == 0) sc[b][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kones, qm[b], zero16, 0, 0, 0);
+    else sc[b][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][st - 1], qf[b][st - 1], sc[b][kb], 0, 0, 0);
+  };
+  // MFMA i (0..7) of O^T += V^T P^T for query block b
+  auto pv_mfma = [&](const int b, const int i) {
+    const int c2 = i >> 1;
+    if (i & 1) o1[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[2 * c2 + 1], pfb[b][c2], o1[b], 0, 0, 0);
+    else o0[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[2 * c2], pfb[b][c2], o0[b], 0, 0, 0);
+  };
+  // Covered MFMA i (0..17) of a softmax pass over block b: P V of the OTHER block (0..7), then its S^T
+  // (8..17).  The empty volatile asm "rewrites" an operand of that MFMA together with t0 / t1 /
+  // t2 (the scores the next two exponentials read and the last exponential's result): the MFMA and those
+  // exponentials can only be emitted after it, and it only after the previous exponentials.  Without
+  // the pin LLVM hoists the 18 MFMAs of a pass into one cluster in front of the exponentials (they do
+  // not depend on each other) — the un-pipelined kernel again.
+#define ATT_COVERED(b, i, t0, t1, t2, t3)                                                            \
+  do {                                                                                             \
+    if ((i) < 8) {                                                                                 \
+      asm volatile("" : "+v"(vf[(i)&7]), "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));                            \
+      pv_mfma(1 - (b), (i));                                                                       \
+    } else if ((i) < 10) {                                                                         \
+      asm volatile("" : "+v"(qm[1 - (b)]), "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));                          \
+      s_mfma(1 - (b), (i) - 8);                                                                    \
+    } else {                                                                                       \
+      asm volatile("" : "+v"(kf[(i) & 1][((((i) - 8) >> 1) - 1) & 3]), "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3)); \
+      s_mfma(1 - (b), (i) - 8);                                                                    \
+    }                                                                                              \
+  } while (0)
+
+  // softmax numerators of query block b for tile kt (scores in sc[b]) -> pfb[b], lsum[b], with the 18
+  // covered MFMAs issued between the exponentials; `extra(i)` runs behind MFMA i (LDS fragment reads)
+  auto softmax = [&](const int b, const int kt, auto&& extra) {
+    f32x16& s0 = sc[b][0];
+    f32x16& s1 = sc[b][1];
+    if (!PRESCALED) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = fmaf(s0[r] + mref[b], c, -mref[b]);
+        s1[r] = fmaf(s1[r] + mref[b], c, -mref[b]);
+      }
+    }
+    if (__builtin_expect((kt << 6) + 64 > S, 0)) {
+      int kb0 = (kt << 6) + 4 * half;
+      asm volatile("" : "+v"(kb0));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb0 + (r & 3) + 8 * (r >> 2);
+        if (key >= S) s0[r] = -INFINITY;
+        if (key + 32 >= S) s1[r] = -INFINITY;
+      }
+    }
+    f16x8 (&pf)[4] = pfb[b];
+    // Every covered MFMA gets its share of the pass's VALU work issued right behind it: two
+    // exponentials (step r), two adds into the denominator (step r - 1) and one fp16 pack (steps r - 2 /
+    // r - 3) — 28 cycles of plain VALU in the 32-cycle shadow of the MFMA.  Measured rules of gfx950
+    // (tools/issue_probe.cpp): a wave's own plain VALU / transcendental instructions run under its
+    // MFMA, ANOTHER wave's do not (two waves of a SIMD cost the sum of their streams), and v_dot2 /
+    // v_pk_*_f32 do not run under an MFMA at all — so the denominator is summed from the fp32
+    // exponentials with v_add_f32 (two chains), not from the packed fp16 values with v_dot2.
+    float lt0 = 0.f, lt1 = 0.f;
+    float e0[16], e1[16];   // exponentials of key half 0 / 1 (a handful live at any time)
+    float dm = 0.f;         // filler for the pins that have fewer than four values to tie
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 18; ++r) {
+      if (r == 0) {
+        ATT_COVERED(b, r, s0[0], s1[0], lt0, dm);
+      } else if (r < 16) {
+        ATT_COVERED(b, r, s0[r], s1[r], e1[r - 1], lt0);
+      } else if (r == 16) {
+        ATT_COVERED(b, r, e0[14], e0[15], e1[15], lt0);
+      } else {
+        ATT_COVERED(b, r, e1[14], e1[15], lt0, dm);
+      }
+      extra(r);
+      if (r >= 1 && r <= 16) {
+        lt0 += e0[r - 1];
+        lt1 += e1[r - 1];
+      }
+      // steps (q, q + 1), q even, are complete after step q + 1: their key-half-0 pair is packed behind
+      // MFMA q + 2, their key-half-1 pair behind MFMA q + 3
+      if (r >= 2 && !(r & 1)) {
+        const int q = r - 2;
+        pf[q >> 3][q & 7] = (f16)e0[q];
+        pf[q >> 3][(q & 7) + 1] = (f16)e0[q + 1];
+      }
+      if (r >= 3 && (r & 1)) {
+        const int q = r - 3;
+        pf[2 + (q >> 3)][q & 7] = (f16)e1[q];
+        pf[2 + (q >> 3)][(q & 7) + 1] = (f16)e1[q + 1];
+      }
+      if (r < 16) {
+        e0[r] = __builtin_amdgcn_exp2f(s0[r]);
+        e1[r] = __builtin_amdgcn_exp2f(s1[r]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float lt = lt0 + lt1;
+    // ---- rare path: move the reference (always on the first tile, which defines it) ----
+    // (one branch, and laid out as unlikely: a TAKEN branch costs a wave hundreds of cycles of
+    //  instruction fetch here, so the common path has to fall through)
+    const bool moved = (kt == 0) | (__builtin_amdgcn_ballot_w64(!(lt <= 128.f)) != 0);
+    if (__builtin_expect(moved, 0)) {
+      float mx = max3_f(s0[0], s1[0], s0[1]);
+      mx = max3_f(mx, s1[1], s0[2]);
+#pragma unroll
+      for (int r = 2; r < 15; ++r) mx = max3_f(mx, s1[r], s0[r + 1]);
+      mx = fmaxf(mx, s1[15]);
+      {
+        const unsigned mu = __float_as_uint(mx);
+        const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      }
+      const bool mv = kt == 0 || mx > 7.0f;
+      const float want = mv ? mref[b] + ceilf(mx) : mref[b];
+      const float nref = (float)(f16)want;
+      const float delta = nref - mref[b];
+      const float alpha = kt == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+      mref[b] = nref;
+      if (half == 0) qm[b][0] = (f16)(-nref);
+      lsum[b] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] -= delta;
+        s1[r] -= delta;
+        o0[b][r] *= alpha;
+        o1[b][r] *= alpha;
+      }
+      lt = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float x0 = __builtin_amdgcn_exp2f(s0[r]), x1 = __builtin_amdgcn_exp2f(s1[r]);
+        pf[r >> 3][r & 7] = (f16)x0;
+        pf[2 + (r >> 3)][r & 7] = (f16)x1;
+        lt += x0 + x1;
+      }
+    }
+    lsum[b] += lt;
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  stage(0);
+  stage(1);
+  stage(2);
+  if (ntiles >= 3) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else if (ntiles == 2) {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  load_k(0);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) s_mfma(0, i);   // S^T of block 0, tile 0: nothing to hide it under yet
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    // ---- softmax (0, kt) over: P V (1, kt-1) [vf = V^T of tile kt-1, zero P on the first tile], S^T (1, kt) ----
+    softmax(0, kt, [&](const int i) {
+      if (i == 7) load_k(kt);
+    });
+    load_v(kt);   // for P V (0, kt) below (after the pass: its rare path needs the registers)
+    // tile kt+1 has landed for every wave (its K is read below); the stage tile kt+3 goes to held
+    // tile kt-1, whose last reader (the V^T fragments of the pass above) is behind this barrier
+    if (kt + 2 < ntiles) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    stage(kt + 3);
+    // ---- softmax (1, kt) over: P V (0, kt), S^T (0, kt+1) ----
+    softmax(1, kt, [&](const int i) {
+      if (i == 7) load_k(kt + 1);   // (past the last tile: stale LDS, those scores are never used)
+    });
+    load_v(kt);   // again, for P V (1, kt) in the next pass / after the loop
+  }
+  // P V (1, last tile)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) pv_mfma(1, i);
+
+  // ---- normalise and store: o{0,1}[r] is O[query l31][d = 32 dt + (r&3) + 8 (r>>2) + 4 half] ----
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    float l = lsum[b];
+    {
+      const unsigned lu = __float_as_uint(l);
+      const auto sw = __builtin_amdgcn_permlane32_swap(lu, lu, false, false);
+      l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    const float inv = 1.0f / l;
+    const int qi = q0 + 32 * b + l31;
+    if (qi < S) {
+      f16* op = out + ((int64_t)frame * S + qi) * ldo + head * 64 + 4 * half;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f16x4 v0, v1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v0[e] = (f16)(o0[b][4 * g + e] * inv);
+          v1[e] = (f16)(o1[b][4 * g + e] * inv);
+        }
+        *(f16x4*)(op + 8 * g) = v0;
+        *(f16x4*)(op + 32 + 8 * g) = v1;
+      }
+    }
+  }
+}
+
 extern "C" int gcd_attn_spatial_f16(const void* qkv, int64_t ld, const void* vt, int S_pad,
                                     void* out, int64_t ldo, int frames, int S, int heads,
                                     int q_prescaled, void* stream) {
@@ -548,13 +884,22 @@ extern "C" int gcd_attn_spatial_f16(const void* qkv, int64_t ld, const void* vt,
   const int impl = gcd_tune_get(GCD_TUNE_ATTN_IMPL);
   // (measured: 72x128 tokens 4245 -> 3483 us, 36x64 553 -> 513 us; 18x32 = 576 tokens would waste a
   //  quarter of its 256-query blocks and runs 92 vs 109 us on the 128-query kernel)
-  const bool wide = impl == 2 || (impl != 1 && S >= 1024);
+  // (impl 2 = the un-pipelined 64-query kernel, kept for A/B runs of tools/attn_bench; 3 / automatic = the
+  //  software-pipelined one: 72x128 tokens 3187 -> 3068 us, 36x64 495 -> 465 us on the same box)
+  const bool wide = impl == 2 || impl == 3 || (impl != 1 && S >= 1024);
   const int qpb = wide ? 256 : 128;
   const int nqb = (S + qpb - 1) / qpb;
   const int64_t nblk = (int64_t)nqb * heads * frames;
   GCD_CHECK_ARG(nblk < (1ll << 31), "gcd_attn_spatial_f16: grid too large");
   const dim3 grid((unsigned)nblk), block(256);
-  if (wide) {
+  if (wide && impl != 2) {
+    if (q_prescaled)
+      hipLaunchKernelGGL(attn_spatial64p_kernel<true>, grid, block, 0, st, (const f16*)qkv, ld,
+                         (const f16*)vt, S_pad, (f16*)out, ldo, S, heads, nqb, c);
+    else
+      hipLaunchKernelGGL(attn_spatial64p_kernel<false>, grid, block, 0, st, (const f16*)qkv, ld,
+                         (const f16*)vt, S_pad, (f16*)out, ldo, S, heads, nqb, c);
+  } else if (wide) {
     if (q_prescaled)
       hipLaunchKernelGGL(attn_spatial64_kernel<true>, grid, block, 0, st, (const f16*)qkv, ld,
                          (const f16*)vt, S_pad, (f16*)out, ldo, S, heads, nqb, c);

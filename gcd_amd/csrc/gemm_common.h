@@ -70,7 +70,7 @@ int gcd_tune_get(int knob);
 #define GCD_EPI_ROW_F32 144                       /* 32 floats + 16 B pad: conflict-free b128 writes */
 #define GCD_EPI_TILE_F32 (32 * GCD_EPI_ROW_F32)   /* one 32 x 32 fp32 tile */
 #define GCD_EPI_ROW_F16 176                       /* GEGLU: 80 fp16 + 16 B pad */
-#define GCD_EPI_STAGE_BYTES 11264                 /* max(2 * 4608, 64 * 176) */
+#define GCD_EPI_STAGE_BYTES 10752                 /* max(2 * 4608, 32 * 176, 32 * 336) */
 
 // Measured on MI355X (tools/gemm_bench, profiles/r01_gemm_epilogue_ablation.txt): the transposed
 // path pays for fp16 outputs (8-byte pieces per row become 64-byte rows: q|k|v projections -7..-12 %)
@@ -303,15 +303,25 @@ __device__ __forceinline__ void gcd_epi_f32_rows_full(const GemmK& p, f32x16 (&a
 
 // a * gelu(g) of a full wave tile (value / gate rows interleaved in 16s by packing.pack_geglu, so both
 // live in the same lane; lb as above).  The wave's 64 x 80 fp16 results go through its LDS stage
-// ([64][80] + 16 B row pad) and leave as 16-byte pieces of 160-byte row segments: 6.4 rows per store
+// ([32][80] + 16 B row pad, twice) and leave as 16-byte pieces of 160-byte row segments: 6.4 rows per store
 // instruction instead of 32 rows x 16 B straight from the accumulator layout, and half as many store
 // instructions (measured -3..-7 % per GEGLU launch, profiles/r01q_gemm_bench_rows.txt).
 __device__ __forceinline__ void gcd_epi_geglu_rows_full(const GemmK& p, f32x16 (&acc)[5][2], int m_base,
                                                         int n_base, int lane, const float* lb, char* stage) {
   const int l31 = lane & 31, hh = lane >> 5;
   const float* lbl = lb + 4 * hh;
+  // row-major [M, N/2], or tile-blocked: tile (tm, tn) = one contiguous [256][160] block (out_blocked)
+  f16* outp = (f16*)p.out + (int64_t)m_base * p.ldo + (n_base >> 1);
+  int64_t rs = p.ldo;
+  if (p.out_blocked) {
+    const int tn = n_base / 320;
+    const int64_t blk = (int64_t)(m_base >> 8) * (p.N / 320) + tn;
+    outp = (f16*)p.out + (blk * 256 + (m_base & 255)) * 160 + ((n_base - tn * 320) >> 1);
+    rs = 160;
+  }
+  // one 32-token half at a time (5.5 KB of stage): the stores of half 0 drain under the GELU of half 1
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < 2; ++j) {
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
@@ -322,23 +332,15 @@ __device__ __forceinline__ void gcd_epi_geglu_rows_full(const GemmK& p, f32x16 (
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           o[e] = (f16)((acc[i][j][4 * g + e] + ba[e]) * gelu_fast(acc[i][j][8 + 4 * g + e] + bg[e]));
-        *(f16x4*)(stage + (32 * j + l31) * GCD_EPI_ROW_F16 + (16 * i + 8 * g + 4 * hh) * 2) = o;
+        *(f16x4*)(stage + l31 * GCD_EPI_ROW_F16 + (16 * i + 8 * g + 4 * hh) * 2) = o;
       }
-  // row-major [M, N/2], or tile-blocked: tile (tm, tn) = one contiguous [256][160] block (out_blocked)
-  f16* outp = (f16*)p.out + (int64_t)m_base * p.ldo + (n_base >> 1);
-  int64_t rs = p.ldo;
-  if (p.out_blocked) {
-    const int tn = n_base / 320;
-    const int64_t blk = (int64_t)(m_base >> 8) * (p.N / 320) + tn;
-    outp = (f16*)p.out + (blk * 256 + (m_base & 255)) * 160 + ((n_base - tn * 320) >> 1);
-    rs = 160;
-  }
 #pragma unroll
-  for (int it = 0; it < 10; ++it) {
-    const int tt = it * 64 + lane;
-    const int row = tt / 10, ch = tt - row * 10;
-    const f16x8 v = *(const f16x8*)(stage + row * GCD_EPI_ROW_F16 + ch * 16);
-    *(f16x8*)(outp + (int64_t)row * rs + ch * 8) = v;
+    for (int it = 0; it < 5; ++it) {
+      const int tt = it * 64 + lane;
+      const int row = tt / 10, ch = tt - row * 10;
+      const f16x8 v = *(const f16x8*)(stage + row * GCD_EPI_ROW_F16 + ch * 16);
+      *(f16x8*)(outp + (int64_t)(32 * j + row) * rs + ch * 8) = v;
+    }
   }
 }
 
@@ -384,45 +386,6 @@ __device__ __forceinline__ void gcd_epilogue_64x160(const GemmK& p, f32x16 (&acc
     for (int i = 0; i < 5; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
-    return;
-  }
-  if ((EV & 16) && p.out_kind == GCD_OUT_GEGLU && p.N % 320 == 0 && (p.ldo & 7) == 0) {
-    // a * gelu(g) in the accumulator layout (value / gate live in the same lane), staged as fp16
-    // [64 rows][80 hidden columns], written out as 160 contiguous bytes per row.
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const int nb = n_base + 32 * i;
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const int c = 8 * g + 4 * hh;
-          f32x4 a, gt;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            a[e] = acc[i][j][4 * g + e];
-            gt[e] = acc[i][j][8 + 4 * g + e];
-          }
-          if (p.bias) {
-            a += *(const f32x4*)(p.bias + nb + c);
-            gt += *(const f32x4*)(p.bias + nb + 16 + c);
-          }
-          f16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (f16)(a[e] * gelu_fast(gt[e]));
-          *(f16x4*)(stage + (32 * j + l31) * GCD_EPI_ROW_F16 + (16 * i + c) * 2) = o;
-        }
-      }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    f16* outp = (f16*)p.out + (n_base >> 1);
-#pragma unroll
-    for (int it = 0; it < 10; ++it) {
-      const int tt = it * 64 + lane;
-      const int row = tt / 10, ch = tt - row * 10;
-      const int m = m_base + row;
-      const f16x8 v = *(const f16x8*)(stage + row * GCD_EPI_ROW_F16 + ch * 16);
-      if (m < p.M) *(f16x8*)(outp + (int64_t)m * p.ldo + ch * 8) = v;
-    }
     return;
   }
   if (p.out_kind == GCD_OUT_GEGLU) {   // ragged N: direct stores from the accumulator layout

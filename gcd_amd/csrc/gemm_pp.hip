@@ -40,7 +40,13 @@ constexpr int PP_A_BYTES = PP_BM * 64;                  // A sub-tile: 256 rows 
 constexpr int PP_W_BYTES = PP_BN * 64;                  // W sub-tile: 320 rows x 32 fp16
 constexpr int PP_SLOT = PP_A_BYTES + PP_W_BYTES;        // 36864
 constexpr int PP_SMEM = 4 * PP_SLOT;                    // 147456: the ring
-constexpr int PP_SMEM_LAUNCH = PP_SMEM + 320 * 4;        // + the epilogue's per-column addends
+// Epilogue staging: 8 wave-private regions of GCD_EPI_STAGE_BYTES that start at slot 2 and run 12 KB past
+// the ring, so that slots 0 and 1 stay free for the NEXT tile's first two sub-tiles while a persistent
+// workgroup is in its epilogue; then two buffers of 320 per-column addends (this tile's / the next's).
+constexpr int PP_STAGE0 = 2 * PP_SLOT;
+constexpr int PP_BIAS0 = PP_STAGE0 + 8 * GCD_EPI_STAGE_BYTES;   // 159744
+static_assert(PP_BIAS0 >= PP_SMEM, "staging must cover the ring's tail");
+constexpr int PP_SMEM_LAUNCH = PP_BIAS0 + 2 * 320 * 4;          // 162304 of the 163840 B of LDS
 constexpr int PP_GROUP_M = 4;
 
 #define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
   // W: group 0 wave w loads pieces 3w .. 3w+2, group 1 wave w' loads 12+2w', 13+2w'
   const int w_first = grp == 0 ? 3 * wave : 12 + 2 * (wave - 4);
   const char* w_base[3] = {nullptr, nullptr, nullptr};
-  float* const lds_bias = (float*)(smem + PP_SMEM);   // 320 staged per-column addends
+  float* lds_bias = (float*)(smem + PP_BIAS0);   // 320 staged per-column addends (of two buffers)
   bool lds_bias_ok = false;   // staged addends cover bias (+ rowvec) of the whole tile
   bool alpha_uni = true;      // one frame_alpha entry serves the whole tile
 
@@ -232,26 +238,35 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
       glds16(w_base[j] + (s_begin + sigma) * 64,
              smem + (sigma & 3) * PP_SLOT + PP_A_BYTES + (w_first + j) * 1024);
   };
-  // prologue in steady-state order: sub-tiles 0, 1 and (group 0: the first part of) 2
-  auto issue_prologue = [&]() {
-    if (grp == 0) {
+  // prologue in steady-state order: sub-tiles 0, 1 (part a) and (group 0: the first part of) 2 (part b)
+  auto issue_prologue_a = [&]() {
 #pragma unroll
-      for (int sg = 0; sg < 2; ++sg) {
-        issue_A(sg);
-        issue_W(0, sg);
-        issue_W(1, sg);
-        issue_W(2, sg);
-      }
-      issue_A(2);
-      issue_W(0, 2);
-    } else {
-#pragma unroll
-      for (int sg = 0; sg < 3; ++sg) {
-        issue_A(sg);
-        issue_W(0, sg);
-        issue_W(1, sg);
-      }
+    for (int sg = 0; sg < 2; ++sg) {
+      issue_A(sg);
+      issue_W(0, sg);
+      issue_W(1, sg);
+      if (grp == 0) issue_W(2, sg);
     }
+  };
+  auto issue_prologue_b = [&]() {
+    issue_A(2);
+    issue_W(0, 2);
+    if (grp != 0) issue_W(1, 2);
+  };
+  // Cross-tile prefetch (persistent kernels): part a of the NEXT tile is issued before this tile's
+  // epilogue (slots 0 / 1 are not staging space), so its HBM / L2 latency and set_tile's address
+  // arithmetic run under the epilogue.  On gfx9 stores share vmcnt with the DMA loads and retire in
+  // order, so the first two counted waits of the next K loop admit the epilogue's `nst` stores (a
+  // LOWER bound of what the epilogue path issued after part a: more only makes the wait stricter).
+  // PLAIN mode only: the conv modes carry tap state through the epilogue, which costs them spills in
+  // the K loop (measured: -20 % on the 3x3 convs), and their long K loops hide little of it anyway.
+  constexpr bool XPF = PERSIST && MODE == GCD_GEMM_PLAIN && !(VAR & (16384 | 8192));
+  int nst = 0;
+  auto wait_sub0 = [&]() {   // "all but the newest 8 + nst pieces have landed"
+    if (nst == 40) PP_VMCNT(48);
+    else if (nst == 20) PP_VMCNT(28);
+    else if (nst == 10) PP_VMCNT(18);
+    else PP_VMCNT(8);
   };
 
   // ---- fragment read addresses (per lane, within a slot) ----
@@ -264,9 +279,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
     rdW[ks] = PP_A_BYTES + (160 * wn + l31) * 64 + ch;
   }
 
+  if (XPF) {
+    set_tile(L);
+    issue_prologue_a();
+  }
   for (; L < L_end; L += L_step) {
-  set_tile(L);
-  issue_prologue();
+  if (!XPF) {
+    set_tile(L);
+    issue_prologue_a();
+  }
+  issue_prologue_b();
 
   f32x16 acc[5][2];
 #pragma unroll
@@ -310,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
   } while (0)
 
   if (S > 2) {
-    PP_VMCNT(8);   // everything of sub-tile 0 has landed (8 newer pieces may still fly)
+    wait_sub0();   // everything of sub-tile 0 has landed (8 newer pieces [+ nst stores] may still fly)
   } else {
     PP_VMCNT(0);
   }
@@ -335,7 +357,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
       issue_A(s + 3);
       issue_W(0, s + 3);
       if (s + 3 < S) {
-        PP_VMCNT(8);   // sub-tile s+1 complete: newer = 5 (s+2) + 3 (first part of s+3)
+        if (XPF && s == 0) wait_sub0();   // the epilogue's stores sit between sub-tiles 1 and 2
+        else PP_VMCNT(8);   // sub-tile s+1 complete: newer = 5 (s+2) + 3 (first part of s+3)
       } else {
         PP_VMCNT(0);
       }
@@ -357,7 +380,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
       issue_W(0, s + 3);
       issue_W(1, s + 3);
       if (s + 3 < S) {
-        PP_VMCNT(8);   // sub-tile s+1 complete: newer = 4 (s+2) + 4 (s+3)
+        if (XPF && s == 0) wait_sub0();
+        else PP_VMCNT(8);   // sub-tile s+1 complete: newer = 4 (s+2) + 4 (s+3)
       } else {
         PP_VMCNT(0);
       }
@@ -371,6 +395,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
   // (opaque copies: keeps the compiler from hoisting the epilogue's address arithmetic above the K
   //  loop, where it would cost registers the loop does not have)
   int wm_base = m0 + 64 * wm, wn_base = n0 + 160 * wn, elane = lane;
+  const int e_m0 = m0;
+  const bool e_bias_ok = lds_bias_ok, e_alpha_uni = alpha_uni;
+  const float* const e_bias = lds_bias;
+  char* const e_stage = smem + PP_STAGE0 + wave * GCD_EPI_STAGE_BYTES;
+  if (XPF && L + L_step < L_end) {   // the next tile's addresses, addends (other buffer) and first DMA
+    lds_bias = (float*)(smem + PP_BIAS0) + (e_bias == (const float*)(smem + PP_BIAS0) ? 320 : 0);
+    set_tile(L + L_step);
+    issue_prologue_a();
+  }
+  nst = 0;
   asm volatile("" : "+s"(wm_base), "+s"(wn_base), "+v"(elane));
   if constexpr ((VAR & 16384) != 0) {   // split-K: raw fp32 partial sums of this K slice
     GemmK q = p;
@@ -384,18 +418,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
     // tile-uniform per-frame vectors / blend factors and at most one residual.
     float sa = p.s_acc, sr1 = p.s_r1;
     if (p.frame_alpha) {
-      const float al = p.frame_alpha[m0 / p.rows_per_alpha];
+      const float al = p.frame_alpha[e_m0 / p.rows_per_alpha];
       sa = 1.0f - al;
       if (p.r1_blend) sr1 *= 1.0f - al;
     }
-    const float* lb = lds_bias + 160 * wn;
-    char* stage = smem + wave * GCD_EPI_STAGE_BYTES;
+    const float* lb = e_bias + 160 * wn;
+    char* stage = e_stage;
     p.R1 ? gcd_epi_f32_rows_full<true, false, false, true>(p, acc, wm_base, wn_base, elane, lb, stage, sa, sr1, 0.f)
          : gcd_epi_f32_rows_full<false, false, false, true>(p, acc, wm_base, wn_base, elane, lb, stage, sa, sr1, 0.f);
+    nst = 40;   // 10 column-block x token-half tiles x 4 row-group stores (the statistics stores come on top)
   } else {
     constexpr int EV = ((VAR >> 6) & 31) | ((VAR & 32768) ? 32 : 0);
-    const bool full = wm_base + 64 <= p.M && wn_base + 160 <= p.N && lds_bias_ok;
-    const float* lb = lds_bias + 160 * wn;
+    const bool full = wm_base + 64 <= p.M && wn_base + 160 <= p.N && e_bias_ok;
+    const float* lb = e_bias + 160 * wn;
 #ifdef GCD_ABLATION_BUILD
     if (EV == 8 && full && p.out_kind == GCD_OUT_GEGLU) {
       // ablation: the product's staged GEGLU epilogue, but every tile of a wave lands on the same 10 KB
@@ -404,33 +439,36 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
       q.out = (f16*)p.out + (int64_t)((blockIdx.x & 255) * 8 + wave) * 64 * 80;
       q.ldo = 80;
       q.out_blocked = 0;
-      gcd_epi_geglu_rows_full(q, acc, 0, 0, elane, lb, smem + wave * GCD_EPI_STAGE_BYTES);
+      gcd_epi_geglu_rows_full(q, acc, 0, 0, elane, lb, e_stage);
     } else
 #endif
     if (EV == 0 && full && p.out_kind == GCD_OUT_GEGLU && (p.ldo & 7) == 0) {
-      gcd_epi_geglu_rows_full(p, acc, wm_base, wn_base, elane, lb, smem + wave * GCD_EPI_STAGE_BYTES);
+      gcd_epi_geglu_rows_full(p, acc, wm_base, wn_base, elane, lb, e_stage);
+      nst = 10;
     } else if (EV == 0 && full && p.out_kind == GCD_OUT_F16 && !p.R1 && !p.R2 && !p.frame_alpha &&
                (p.ldo & 7) == 0) {
-      gcd_epi_f16_rows_full(p, acc, wm_base, wn_base, elane, lb, smem + wave * GCD_EPI_STAGE_BYTES);
-    } else if (EV == 0 && full && alpha_uni && p.out_kind == GCD_OUT_F16 && p.R1 && p.R2 && (p.ldo & 3) == 0) {
+      gcd_epi_f16_rows_full(p, acc, wm_base, wn_base, elane, lb, e_stage);
+      nst = 20;
+    } else if (EV == 0 && full && e_alpha_uni && p.out_kind == GCD_OUT_F16 && p.R1 && p.R2 && (p.ldo & 3) == 0) {
       float sa = p.s_acc, sr1 = p.s_r1, sr2 = p.s_r2;
       if (p.frame_alpha) {
-        const float al = p.frame_alpha[m0 / p.rows_per_alpha];
+        const float al = p.frame_alpha[e_m0 / p.rows_per_alpha];
         sa = 1.0f - al;
         sr2 = al;
         if (p.r1_blend) sr1 *= 1.0f - al;
       }
       gcd_epi_f32_rows_full<true, true, true>(p, acc, wm_base, wn_base, elane, lb,
-                                              smem + wave * GCD_EPI_STAGE_BYTES, sa, sr1, sr2);
-    } else if (EV == 0 && full && alpha_uni && p.out_kind == GCD_OUT_F32) {
+                                              e_stage, sa, sr1, sr2);
+      nst = 40;
+    } else if (EV == 0 && full && e_alpha_uni && p.out_kind == GCD_OUT_F32) {
       float sa = p.s_acc, sr1 = p.s_r1, sr2 = p.s_r2;
       if (p.frame_alpha) {
-        const float al = p.frame_alpha[m0 / p.rows_per_alpha];
+        const float al = p.frame_alpha[e_m0 / p.rows_per_alpha];
         sa = 1.0f - al;
         sr2 = al;
         if (p.r1_blend) sr1 *= 1.0f - al;
       }
-      char* stage = smem + wave * GCD_EPI_STAGE_BYTES;
+      char* stage = e_stage;
       if (p.R2) {
         p.R1 ? gcd_epi_f32_rows_full<true, true>(p, acc, wm_base, wn_base, elane, lb, stage, sa, sr1, sr2)
                    : gcd_epi_f32_rows_full<false, true>(p, acc, wm_base, wn_base, elane, lb, stage, sa, sr1, sr2);
@@ -438,11 +476,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
         p.R1 ? gcd_epi_f32_rows_full<true, false>(p, acc, wm_base, wn_base, elane, lb, stage, sa, sr1, sr2)
                    : gcd_epi_f32_rows_full<false, false>(p, acc, wm_base, wn_base, elane, lb, stage, sa, sr1, sr2);
       }
+      nst = 40;
     } else {
       // ragged edge tiles, fp16 outputs, a rowvec / alpha that changes inside the tile
-      gcd_epilogue_64x160<EV>(p, acc, wm_base, wn_base, elane, smem + wave * GCD_EPI_STAGE_BYTES);
+      gcd_epilogue_64x160<EV>(p, acc, wm_base, wn_base, elane, e_stage);
     }
   }
+  if (!XPF) nst = 0;   // without the prefetch every DMA piece of the next tile is younger than the stores
   if (PERSIST) __syncthreads();   // epilogue LDS use vs the next tile's prologue DMA
   }   // tile loop
 }
