@@ -555,8 +555,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64_kernel(const f16* __res
 // <= 2^-12 relative, unbiased).  The K and V^T fragments are read from LDS once per query block
 // instead of once per tile (their registers are live for half a pass each), the ring has four stages and
 // the barrier sits between the two passes (tile kt+1's K is needed from the second one on); the rare
-// "reference moved" path is ONE branch laid out as unlikely — a taken branch costs a wave hundreds of
-// cycles of instruction fetch (two taken branches per pass were 27 % of a lone wave's time).
+// "reference moved" path is ONE branch (no short-circuit) laid out as unlikely: in its inline two-branch
+// form the check cost a lone wave 27 % of its time (a taken branch by itself is ~44 cycles; the rest was
+// scheduling the inline rare block took away from the common path).
 // Measured (tools/attn_bench, same box): 72x128 tokens 3187 -> 3068 us, 36x64 495 -> 465 us; SQ counters
 // of the new kernel: VALU issue 37 % of wave cycles (x 2 waves = 73 % of the SIMD), MFMA busy 51 %, 27 %
 // parked on s_waitcnt / s_barrier.  The 64 v_exp_f32 per wave and tile (16 VALU-port cycles each by the
@@ -760,8 +761,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial64p_kernel(const f16* __re
     }
     float lt = lt0 + lt1;
     // ---- rare path: move the reference (always on the first tile, which defines it) ----
-    // (one branch, and laid out as unlikely: a TAKEN branch costs a wave hundreds of cycles of
-    //  instruction fetch here, so the common path has to fall through)
+    // (one branch, laid out as unlikely: the common path falls through; see the kernel's header)
     const bool moved = (kt == 0) | (__builtin_amdgcn_ballot_w64(!(lt <= 128.f)) != 0);
     if (__builtin_expect(moved, 0)) {
       float mx = max3_f(s0[0], s1[0], s0[1]);

@@ -10,7 +10,7 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { S_NONE = 0, S_MFMA, S_EXP, S_FMA, S_PKFMA, S_MFMA_EXP2, S_MFMA_FMA7, S_MFMA_EXP1, S_CVT, S_MFMA_DEP, S_V1, S_V2, S_V3, S_V4, S_V5, S_V6, S_V7, S_V8, S_V9, S_W0, S_W1, S_W2, S_W3, S_W4, S_W5 };
+enum { S_NONE = 0, S_MFMA, S_EXP, S_FMA, S_PKFMA, S_MFMA_EXP2, S_MFMA_FMA7, S_MFMA_EXP1, S_CVT, S_MFMA_DEP, S_V1, S_V2, S_V3, S_V4, S_V5, S_V6, S_V7, S_V8, S_V9, S_W0, S_W1, S_W2, S_W3, S_W4, S_W5, S_BR0, S_BR1, S_BR2 };
 
 template <int KIND>
 __device__ __forceinline__ void run_stream(int iters, float seed, float* sink) {
@@ -219,6 +219,24 @@ __device__ __forceinline__ void run_stream(int iters, float seed, float* sink) {
         }
       }
       v[0] = p0; v[1] = p1;
+    } else if (KIND == S_BR0 || KIND == S_BR1 || KIND == S_BR2) {
+      // 4 x { 8 fma, a uniform branch around a block of 128 (BR1) / 16 (BR2) fma that is never executed };
+      // BR0: the same 32 fma without the branches.  Prices a TAKEN forward branch.
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[i]) : "v"(seed));
+        if (KIND != S_BR0) {
+          const int z = __builtin_amdgcn_readfirstlane(iters > (1 << 30) ? 1 : 0);   // 0
+          if (KIND == S_BR1)
+            asm volatile("s_cmp_eq_u32 %1, 0\n\ts_cbranch_scc1 1f\n\t.rept 128\n\tv_fma_f32 %0, %0, %0, %0\n\t.endr\n1:"
+                         : "+v"(v[r]) : "s"(z) : "scc");
+          else
+            asm volatile("s_cmp_eq_u32 %1, 0\n\ts_cbranch_scc1 1f\n\t.rept 16\n\tv_fma_f32 %0, %0, %0, %0\n\t.endr\n1:"
+                         : "+v"(v[r]) : "s"(z) : "scc");
+          asm volatile("" ::: "memory");
+        }
+      }
     } else if (KIND == S_MFMA_FMA7) {   // 16 x { MFMA, 7 fma }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -323,5 +341,9 @@ int main() {
   run<S_W4, S_NONE>("X=W3, exps read last iteration's MFMA results  Y=-", 96, 0);
   run<S_W5, S_NONE>("X=W3 + 16 cvt_pk tail                          Y=-", 112, 0);
   run<S_W3, S_W3>("X={nop, M, e, e, add(prev), add(prev)}         Y=same", 96, 96);
+  run<S_BR0, S_NONE>("X=4 x 8 fma, no branches                              Y=-", 32, 0);
+  run<S_BR1, S_NONE>("X=4 x {8 fma, branch over 128 dead instructions}      Y=-", 32, 0);
+  run<S_BR2, S_NONE>("X=4 x {8 fma, branch over 16 dead instructions}       Y=-", 32, 0);
+  run<S_BR1, S_BR1>("X=4 x {8 fma, branch over 128 dead instructions}      Y=same", 32, 32);
   return 0;
 }
