@@ -620,9 +620,11 @@ def test_layernorm(gpu, M, C):
 
 
 # ------------------------------------------------------------------------------------- attention
-@pytest.fixture(params=[0, 1, 2], ids=["attn-auto", "attn-q32", "attn-q64"])
+@pytest.fixture(params=[0, 1, 2, 3], ids=["attn-auto", "attn-q32", "attn-q64", "attn-q64p"])
 def attn_impl(request, gpu):
-    """Both spatial-attention kernels (32 / 64 queries per wave) over the same cases."""
+    """The three spatial-attention kernels (32 queries per wave; 64 per wave; 64 per wave software-pipelined
+    = what "auto" picks for S >= 1024) over the same cases — forced, so the pipelined kernel also sees 1-, 2-
+    and 3-tile sequences and the reference-shift case."""
     from gcd_amd import ops
     ops.tune_set(ops.TUNE_ATTN_IMPL, request.param)
     yield request.param
