@@ -16,7 +16,7 @@ plugin surface.  YAML `target:` strings that pointed at `sgm.modules.diffusionmo
     loss_fn_config.target        gcd_amd.training.StandardDiffusionLoss          (fine-tune step, a vertical slice)
 
 Beside the sockets: gcd_amd.parallel (clip sharding over GPUs), gcd_amd.camera (pose trajectories),
-gcd_amd.metrics (PSNR / SSIM of the evaluation script), gcd_amd.autograd_ops (HIP-backed autograd operators).
+gcd_amd.metrics (PSNR / SSIM of the evaluation script), gcd_amd.eval_io (its frame / video writer), gcd_amd.autograd_ops (HIP-backed autograd operators).
 
 All arithmetic runs in libgcd_amd.so (hand-written HIP, C ABI in include/gcd_amd.h); importing the
 package does not load it, using any op does — and raises if it is missing.
