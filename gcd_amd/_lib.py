@@ -11,7 +11,7 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libgcd_amd.so"
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # GEMM modes / output kinds (mirror include/gcd_amd.h)
 GEMM_PLAIN, GEMM_CONV3X3, GEMM_TEMPORAL3 = 0, 1, 2
@@ -87,6 +87,8 @@ SIGNATURES = {
     "gcd_geglu_fwd_f32": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),
     "gcd_geglu_bwd_f32": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _vp]),
     "gcd_softmax_bwd_rows": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _f, _vp]),
+    "gcd_attn_spatial_bwd_ws_bytes": (_i64, [_i, _i, _i]),
+    "gcd_attn_spatial_bwd": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _f, _vp]),
     "gcd_attn_temporal_bwd": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
     "gcd_cast_scale_f32_f16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _f, _vp]),
     "gcd_cast_f32_bf16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),

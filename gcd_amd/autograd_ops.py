@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import Optional
 
 import torch
@@ -33,18 +34,36 @@ _f32 = torch.float32
 _f16 = torch.float16
 _bf16 = torch.bfloat16
 
-# Operand type of the BACKWARD contractions (dX = dY W, dW = dY^T X): "fp16" (default; incoming gradients
-# are rounded to fp16, the caller applies a static loss scale so that small values survive) or "bf16"
-# (gcd_gemm_desc.operand_bf16 on the general GEMM kernel: fp32's exponent range, no loss scale needed,
-# 8 significant bits).  The forward pass is fp16 either way.  Set through `set_grad_dtype`.
+# Operand type of the GEMM-family contractions (every Linear / Conv2d / Conv3d product):
+#   FWD_DTYPE   the forward pass,      GRAD_DTYPE   the backward pass (dX = dY W, dW = dY^T X)
+# "fp16" (default; the inference engine's arithmetic) or "bf16" (BASELINE.json cfg4 names bf16:
+# gcd_gemm_desc.operand_bf16 — v_mfma_f32_32x32x16_bf16 on the ping-pong kernel, same rate as fp16 on
+# gfx950; fp32's exponent range at 8 significant bits).  The attention cores (softmax(QK^T)V and its
+# backward) keep fp16 operands with an fp32 softmax in both modes, so the static loss scale stays.
+FWD_DTYPE = os.environ.get("GCD_TRAIN_FWD_DTYPE", "fp16")
 GRAD_DTYPE = os.environ.get("GCD_TRAIN_GRAD_DTYPE", "fp16")
 
 
-def set_grad_dtype(name: str) -> None:
-    global GRAD_DTYPE
+def _chk_dtype(name: str) -> str:
     if name not in ("fp16", "bf16"):
-        raise ValueError("grad dtype must be 'fp16' or 'bf16'")
-    GRAD_DTYPE = name
+        raise ValueError("dtype must be 'fp16' or 'bf16'")
+    return name
+
+
+def set_grad_dtype(name: str) -> None:
+    """Operand type of the backward contractions only."""
+    global GRAD_DTYPE
+    GRAD_DTYPE = _chk_dtype(name)
+
+
+def set_train_dtype(name: str) -> None:
+    """Operand type of every GEMM-family contraction of the fine-tune step, forward and backward."""
+    global FWD_DTYPE, GRAD_DTYPE
+    FWD_DTYPE = GRAD_DTYPE = _chk_dtype(name)
+
+
+def _dt(name: str) -> torch.dtype:
+    return _bf16 if name == "bf16" else _f16
 
 
 def _stream():
@@ -56,68 +75,102 @@ def _ld(t):
     return t.stride(0)
 
 
-def _cast16(x32: torch.Tensor) -> torch.Tensor:
-    """fp32 [M, C] (any row stride) -> contiguous fp16."""
-    y = torch.empty(x32.shape, dtype=_f16, device=x32.device)
-    ops.cast_f16(x32, y)
+def _cast16(x32: torch.Tensor, dtype: torch.dtype = _f16) -> torch.Tensor:
+    """fp32 [M, C] (any row stride) -> contiguous fp16 / bf16."""
+    y = torch.empty(x32.shape, dtype=dtype, device=x32.device)
+    (ops.cast_bf16 if dtype == _bf16 else ops.cast_f16)(x32, y)
     return y
 
 
 def _cast16_into(x32: torch.Tensor, y16: torch.Tensor) -> None:
-    """fp32 -> fp16 into a (possibly wider) buffer's leading columns; the 4-channel ends of the UNet go
+    """fp32 -> fp16 / bf16 into a (possibly wider) buffer's leading columns; the 4-channel ends of the UNet go
     through a plain copy (the cast kernel moves 8 channels per lane)."""
     if x32.shape[1] % 8 == 0:
-        ops.cast_f16(x32, y16)
+        (ops.cast_bf16 if y16.dtype == _bf16 else ops.cast_f16)(x32, y16)
     else:
         y16.copy_(x32)
 
 
-def _t16_padded(x16: torch.Tensor, granule: int = 32) -> torch.Tensor:
+def _as_dtype(x16: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """A saved 16-bit operand in the other 16-bit type (forward and backward operand types differ)."""
+    if x16.dtype == dtype:
+        return x16
+    if dtype == _bf16 and x16.is_contiguous():
+        y = torch.empty(x16.shape, dtype=_bf16, device=x16.device)
+        ops.cast_bf16(x16, y)
+        return y
+    return x16.to(dtype)
+
+
+def _t16_padded(x16: torch.Tensor, granule: int = 64) -> torch.Tensor:
     """[R, C] fp16 / bf16 -> [C, Rp] with Rp = R rounded up to the GEMM's K granule and zero padding (a
     GEMM operand whose contraction axis is the token axis)."""
     R, Cc = x16.shape
     Rp = (R + granule - 1) // granule * granule
-    out = torch.zeros(Cc, Rp, dtype=x16.dtype, device=x16.device) if Rp != R else \
-        torch.empty(Cc, Rp, dtype=x16.dtype, device=x16.device)
+    out = torch.empty(Cc, Rp, dtype=x16.dtype, device=x16.device)
+    if Rp != R:
+        out[:, R:].zero_()
     ops.transpose_f16(x16, out[:, :R])
     return out
 
 
-def _to_bf16(x: torch.Tensor) -> torch.Tensor:
-    y = torch.empty(x.shape, dtype=_bf16, device=x.device)
-    ops.cast_bf16(x, y)
-    return y
+_WS = {}
 
 
-def _grad_contractions(dy32: torch.Tensor, x16: torch.Tensor, w_t16: torch.Tensor, need_dx: bool,
-                       need_dw: bool):
+def _train_ws(device) -> torch.Tensor:
+    """Split-K scratch of the fine-tune step: the weight gradients are few-tile GEMMs whose contraction runs
+    over all tokens (gcd_gemm_f16 splits K up to 32 ways when the scratch holds the partial sums), 384 MB."""
+    key = torch.device(device).index or 0
+    w = _WS.get(key)
+    if w is None:
+        w = torch.empty(96 << 20, dtype=_f32, device=device)
+        _WS[key] = w
+    return w
+
+
+_ATTN_WS = {}
+
+
+def _attn_ws(device, nbytes: int) -> torch.Tensor:
+    key = torch.device(device).index or 0
+    w = _ATTN_WS.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ATTN_WS[key] = w
+    return w
+
+
+def _gemm(a16, w16, out, **kw):
+    return ops.gemm(a16, w16, out, operand_bf16=a16.dtype == _bf16, workspace=_train_ws(a16.device), **kw)
+
+
+def _grad_contractions(dy32: torch.Tensor, x16: torch.Tensor, w_t16, need_dx: bool, need_dw: bool):
     """The two contractions every Linear-shaped backward needs, on gcd_gemm_f16:
-         dX [M, K] = dY [M, N] @ W [N, K]      (w_t16 = W^T, [K, N], fp16)
-         dW [N, K] = dY^T [N, M] @ X [M, K]    (x16 fp16 [M, K])
-    in fp16 (default) or bf16 operands (GRAD_DTYPE; bf16 needs 64-deep contraction axes, else fp16)."""
+         dX [M, K] = dY [M, N] @ W [N, K]      (w_t16() -> W^T, [K, N], in the backward operand type)
+         dW [N, K] = dY^T [N, M] @ X [M, K]    (x16 [M, K]; split-K over the tokens)
+    in GRAD_DTYPE operands."""
     M, N = dy32.shape
-    K = w_t16.shape[0]
     dev = dy32.device
-    bf = GRAD_DTYPE == "bf16" and N % 64 == 0
-    dy16 = _to_bf16(dy32) if bf else _cast16(dy32)
+    dt = _dt(GRAD_DTYPE)
+    dy16 = _cast16(dy32, dt)
     dx = dw = None
     if need_dx:
+        wt = w_t16(dt)
+        K = wt.shape[0]
         dx = torch.empty(M, K, dtype=_f32, device=dev)
-        wt = w_t16.to(_bf16) if bf else w_t16
         if N % 32 == 0:
-            ops.gemm(dy16, wt, dx, M=M, operand_bf16=bf)
+            _gemm(dy16, wt, dx, M=M)
         else:   # N a multiple of 16 only (the padded last conv): widen the contraction axis with zeros
-            Np = (N + 31) // 32 * 32
-            dyp = torch.zeros(M, Np, dtype=_f16, device=dev)
+            Np = (N + 63) // 64 * 64
+            dyp = torch.zeros(M, Np, dtype=dt, device=dev)
             dyp[:, :N] = dy16
-            wtp = torch.zeros(K, Np, dtype=_f16, device=dev)
+            wtp = torch.zeros(K, Np, dtype=dt, device=dev)
             wtp[:, :N] = wt
-            ops.gemm(dyp, wtp, dx, M=M)
+            _gemm(dyp, wtp, dx, M=M)
     if need_dw:
+        K = x16.shape[1]
         dw = torch.empty(N, K, dtype=_f32, device=dev)
-        g = 64 if bf else 32
-        xs = _to_bf16(x16) if bf else x16
-        ops.gemm(_t16_padded(dy16, g), _t16_padded(xs, g), dw, M=N, operand_bf16=bf)
+        _gemm(_t16_padded(dy16), _t16_padded(_as_dtype(x16, dt)), dw, M=N)
     return dx, dw
 
 
@@ -131,23 +184,52 @@ def _colsum(x32: torch.Tensor, rows_per_block: Optional[int] = None) -> torch.Te
 
 
 class _PackCache:
-    """fp16 operand forms of a parameter, rebuilt when the parameter changes (torch's version counter;
-    `clear()` after an optimizer step that writes through raw pointers).  Keyed by storage address and
-    shape, not by Python object: under activation checkpointing the backward pass sees the parameter
-    through a different tensor object than the forward did."""
+    """fp16 / bf16 operand forms of the parameters of ATTACHED modules, rebuilt when a parameter changes
+    (torch's version counter; `clear()` after an optimizer step that writes through raw pointers).
+
+    Under activation checkpointing the backward pass sees a parameter through a detached alias, not the
+    nn.Parameter object, so entries are looked up by storage address — but ONLY through the registry of
+    `attach`: an address is trusted when a still-alive registered parameter of the same shape lives there
+    (then the tensor in hand aliases that parameter's storage).  Anything else — temporaries such as a
+    concatenated weight, tensors of an un-attached or rebuilt model — is packed and never kept: a freed
+    temporary's address is handed out again by the caching allocator, and an address / version key alone
+    would return the previous owner's weights."""
 
     def __init__(self):
         self._d = {}
+        self._reg = {}          # data_ptr -> weakref to the nn.Parameter that owns the storage
+
+    def attach(self, module: torch.nn.Module) -> None:
+        """Register the module's parameters (idempotent, cheap: one dict probe per parameter)."""
+        for q in module.parameters():
+            r = self._reg.get(q.data_ptr())
+            if r is None or r() is not q:
+                self._reg[q.data_ptr()] = weakref.ref(q)
+
+    def _owner(self, p: torch.Tensor):
+        r = self._reg.get(p.data_ptr())
+        q = None if r is None else r()
+        # (a reshaped view of the whole parameter, e.g. a 1x1 convolution's [Cout, Cin, 1, 1] as [Cout, Cin], counts)
+        if q is None or q.data_ptr() != p.data_ptr() or q.numel() != p.numel():
+            return None
+        return q
 
     def get(self, p: torch.Tensor, kind: str, fn):
-        if not p.is_leaf:          # a temporary (e.g. the concatenated q|k|v weight): pack, do not keep
-            return fn(p.detach())
-        key = (p.data_ptr(), tuple(p.shape), kind)
+        return self.get_multi((p,), kind, lambda ps: fn(ps[0]))
+
+    def get_multi(self, ps, kind: str, fn):
+        """One packed form of several parameters (e.g. the concatenated q|k|v weight): cached when every one
+        of them is a registered parameter, keyed on all their addresses and versions."""
+        owners = [self._owner(p) for p in ps]
+        if any(q is None for q in owners):
+            return fn([p.detach() for p in ps])
+        key = (tuple(q.data_ptr() for q in owners), tuple(tuple(q.shape) for q in owners), kind)
+        ver = tuple(q._version for q in owners)
         hit = self._d.get(key)
-        if hit is not None and hit[0] == p._version:
+        if hit is not None and hit[0] == ver:
             return hit[1]
-        v = fn(p.detach())
-        self._d[key] = (p._version, v)
+        v = fn([p.detach() for p in ps])
+        self._d[key] = (ver, v)
         return v
 
     def clear(self):
@@ -160,6 +242,14 @@ PACK = _PackCache()
 # ------------------------------------------------------------------------------------------------
 # Linear:  y = x @ W^T + b            (attention.py q/k/v/out, FeedForward, proj_in/out, emb MLPs)
 # ------------------------------------------------------------------------------------------------
+def _pack_lin(dt):
+    return lambda w: w.detach().to(dt).contiguous()
+
+
+def _pack_lin_t(dt):
+    return lambda w: w.detach().t().to(dt).contiguous()      # [K, N], one rounding from the fp32 parameter
+
+
 class Linear16(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -168,10 +258,11 @@ class Linear16(torch.autograd.Function):
         N = weight.shape[0]
         if K % 32 or N % 16:
             raise NotImplementedError(f"Linear16: K={K} must be a multiple of 32 and N={N} of 16")
-        x16 = _cast16(x)
-        w16 = PACK.get(weight, "lin", packing.pack_linear)
+        dt = _dt(FWD_DTYPE)
+        x16 = _cast16(x, dt)
+        w16 = PACK.get(weight, f"lin_{FWD_DTYPE}", _pack_lin(dt))
         y = torch.empty(M, N, dtype=_f32, device=x.device)
-        ops.gemm(x16, w16, y, M=M, bias=None if bias is None else bias.detach().float())
+        _gemm(x16, w16, y, M=M, bias=None if bias is None else bias.detach().float())
         ctx.save_for_backward(x16, weight)
         ctx.has_bias = bias is not None
         return y
@@ -179,12 +270,10 @@ class Linear16(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x16, weight = ctx.saved_tensors
-        M, K = x16.shape
-        N = weight.shape[0]
         dy = dy.contiguous()
         db = None
-        wt16 = PACK.get(weight, "lin_t", lambda w: w.t().contiguous().to(_f16))     # [K, N]
-        dx, dw = _grad_contractions(dy, x16, wt16, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dx, dw = _grad_contractions(dy, x16, lambda dt: PACK.get(weight, f"lin_t_{dt}", _pack_lin_t(dt)),
+                                    ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dy)[0]
         return dx, dw, db
@@ -194,9 +283,59 @@ def linear(x, weight, bias=None):
     return Linear16.apply(x, weight, bias)
 
 
+class QKVLinear16(torch.autograd.Function):
+    """q | k | v = x @ [Wq; Wk; Wv]^T as ONE GEMM (attention.py:281-296 runs three).  The concatenated operand
+    is packed from the three parameters and cached on all three (PACK.get_multi) — there is no concatenated
+    weight tensor in the graph whose storage could be recycled."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv):
+        ops._need_gpu(x, wq)
+        M, K = x.shape
+        dt = _dt(FWD_DTYPE)
+        x16 = _cast16(x, dt)
+        w16 = PACK.get_multi((wq, wk, wv), f"qkv_{FWD_DTYPE}",
+                             lambda ws: torch.cat([w.to(dt) for w in ws], 0).contiguous())
+        y = torch.empty(M, w16.shape[0], dtype=_f32, device=x.device)
+        _gemm(x16, w16, y, M=M)
+        ctx.save_for_backward(x16, wq, wk, wv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16, wq, wk, wv = ctx.saved_tensors
+        dy = dy.contiguous()
+        need_dw = any(ctx.needs_input_grad[1:4])
+        dx, dw = _grad_contractions(
+            dy, x16,
+            lambda dt: PACK.get_multi((wq, wk, wv), f"qkv_t_{dt}",
+                                      lambda ws: torch.cat([w.t().to(dt) for w in ws], 1).contiguous()),
+            ctx.needs_input_grad[0], need_dw)
+        dq = dk = dv = None
+        if dw is not None:
+            n = wq.shape[0]
+            dq, dk, dv = dw[:n], dw[n:2 * n], dw[2 * n:]
+        return dx, dq, dk, dv
+
+
+def qkv_linear(x, wq, wk, wv):
+    return QKVLinear16.apply(x, wq, wk, wv)
+
+
 # ------------------------------------------------------------------------------------------------
 # Conv2d 3x3 as implicit GEMM over token-major activations (stride 1 / 2, fused x2 nearest upsample)
 # ------------------------------------------------------------------------------------------------
+def _pack_c3(dt, cin_p, cout_p):
+    return lambda w: packing.pack_conv3x3(w, cin_pad=cin_p, cout_pad=cout_p, dtype=dt)
+
+
+def _pack_c3_dgrad(dt, cin_p, cout_p):
+    """The dgrad of a stride-1 3x3 convolution is a 3x3 convolution of dY with the taps mirrored and the
+    channel roles exchanged: W'[cin][kh][kw][cout] = W[cout][cin][2-kh][2-kw]."""
+    return lambda w: packing.pack_conv3x3(w.detach().permute(1, 0, 2, 3).flip(2, 3), cin_pad=cout_p,
+                                          cout_pad=cin_p, dtype=dt)
+
+
 class Conv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, frames, Hi, Wi, stride, upsample):
@@ -210,20 +349,20 @@ class Conv3x3(torch.autograd.Function):
             Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
         Min, Mout = frames * Hi * Wi, frames * Ho * Wo
         assert x.shape == (Min, Cin)
-        x16 = torch.zeros(Min, cin_p, dtype=_f16, device=x.device) if cin_p != Cin else None
-        if x16 is None:
-            x16 = _cast16(x)
-        else:
+        dt = _dt(FWD_DTYPE)
+        if cin_p != Cin:
+            x16 = torch.zeros(Min, cin_p, dtype=dt, device=x.device)
             _cast16_into(x, x16[:, :Cin])
-        w16 = PACK.get(weight, f"c3_{cin_p}_{cout_p}",
-                       lambda w: packing.pack_conv3x3(w, cin_pad=cin_p, cout_pad=cout_p))
+        else:
+            x16 = _cast16(x, dt)
+        w16 = PACK.get(weight, f"c3_{cin_p}_{cout_p}_{FWD_DTYPE}", _pack_c3(dt, cin_p, cout_p))
         b = None
         if bias is not None:
             b = torch.zeros(cout_p, dtype=_f32, device=x.device)
             b[:Cout] = bias.detach().float()
         y = torch.empty(Mout, cout_p, dtype=_f32, device=x.device)
         geo = dict(Cin=cin_p, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo, stride=stride, upsample=int(upsample))
-        ops.gemm(x16, w16, y, M=Mout, mode=GEMM_CONV3X3, bias=b, conv=geo)
+        _gemm(x16, w16, y, M=Mout, mode=GEMM_CONV3X3, bias=b, conv=geo)
         ctx.save_for_backward(x16, weight)
         ctx.geo, ctx.frames, ctx.dims = geo, frames, (Cin, Cout, cin_p, cout_p)
         ctx.has_bias = bias is not None
@@ -234,34 +373,47 @@ class Conv3x3(torch.autograd.Function):
         x16, weight = ctx.saved_tensors
         Cin, Cout, cin_p, cout_p = ctx.dims
         geo, frames = ctx.geo, ctx.frames
-        Mout = frames * geo["Ho"] * geo["Wo"]
-        Min = frames * geo["Hi"] * geo["Wi"]
+        Hi, Wi, Ho, Wo = geo["Hi"], geo["Wi"], geo["Ho"], geo["Wo"]
+        Mout, Min = frames * Ho * Wo, frames * Hi * Wi
         dev = dy.device
         dyp = dy.contiguous()
         if cout_p != Cout:
             dyp = torch.zeros(Mout, cout_p, dtype=_f32, device=dev)
             dyp[:, :Cout] = dy
         lib = _lib.load()
-        w16 = PACK.get(weight, f"c3_{cin_p}_{cout_p}",
-                       lambda w: packing.pack_conv3x3(w, cin_pad=cin_p, cout_pad=cout_p))     # [cout_p, 9*cin_p]
-        wt16 = PACK.get(weight, f"c3t_{cin_p}_{cout_p}", lambda w: w16.t().contiguous())      # [9*cin_p, cout_p]
-        col = None
-        if ctx.needs_input_grad[1]:
-            col = torch.empty(Mout, 9 * cin_p, dtype=_f16, device=dev)
-            check(lib.gcd_im2col3x3_f16(x16.data_ptr(), _ld(x16), col.data_ptr(), frames, cin_p, geo["Hi"],
-                                        geo["Wi"], geo["Ho"], geo["Wo"], geo["stride"], geo["upsample"], 0,
-                                        _stream()), "gcd_im2col3x3_f16")
-        # the convolution as a Linear over im2col rows: dcol = dY W, dW = dY^T col
-        dcol, dwp = _grad_contractions(dyp, col if col is not None else x16[:, :0], wt16,
-                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dt = _dt(GRAD_DTYPE)
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dx = dw = db = None
-        if dcol is not None:
+        dy16 = _cast16(dyp, dt)
+        if need_dx and geo["stride"] == 1:
+            # dgrad as an implicit-GEMM convolution of dY on the forward kernel (no dcol tensor, no col2im):
+            # at the output resolution; a fused x2 upsample then sums every 2 x 2 block back onto its source
+            wd = PACK.get(weight, f"c3d_{cin_p}_{cout_p}_{GRAD_DTYPE}", _pack_c3_dgrad(dt, cin_p, cout_p))
+            dxo = torch.empty(Mout, cin_p, dtype=_f32, device=dev)
+            _gemm(dy16, wd, dxo, M=Mout, mode=GEMM_CONV3X3,
+                  conv=dict(Cin=cout_p, Hi=Ho, Wi=Wo, Ho=Ho, Wo=Wo, stride=1, upsample=0))
+            if geo["upsample"]:
+                dxo = dxo.reshape(frames, Hi, 2, Wi, 2, cin_p).sum(dim=(2, 4)).reshape(Min, cin_p)
+            dx = dxo[:, :Cin] if cin_p != Cin else dxo
+        col = None
+        if need_dw or (need_dx and dx is None):
+            xg = _as_dtype(x16, dt)
+            col = torch.empty(Mout, 9 * cin_p, dtype=dt, device=dev)
+            check(lib.gcd_im2col3x3_f16(xg.data_ptr(), _ld(xg), col.data_ptr(), frames, cin_p, Hi, Wi, Ho, Wo,
+                                        geo["stride"], geo["upsample"], 0, _stream()), "gcd_im2col3x3_f16")
+        if need_dx and dx is None:
+            # stride 2 (the three Downsample convs): dcol = dY W by a plain GEMM, then the col2im gather
+            wt = PACK.get(weight, f"c3t_{cin_p}_{cout_p}_{GRAD_DTYPE}",
+                          lambda w: _pack_c3(dt, cin_p, cout_p)(w).t().contiguous())      # [9*cin_p, cout_p]
+            dcol = torch.empty(Mout, 9 * cin_p, dtype=_f32, device=dev)
+            _gemm(dy16, wt, dcol, M=Mout)
             dxp = torch.empty(Min, cin_p, dtype=_f32, device=dev)
-            check(lib.gcd_col2im3x3_f32(dcol.data_ptr(), dxp.data_ptr(), cin_p, frames, cin_p, geo["Hi"],
-                                        geo["Wi"], geo["Ho"], geo["Wo"], geo["stride"], geo["upsample"], 0,
-                                        _stream()), "gcd_col2im3x3_f32")
+            check(lib.gcd_col2im3x3_f32(dcol.data_ptr(), dxp.data_ptr(), cin_p, frames, cin_p, Hi, Wi, Ho, Wo,
+                                        geo["stride"], geo["upsample"], 0, _stream()), "gcd_col2im3x3_f32")
             dx = dxp[:, :Cin] if cin_p != Cin else dxp
-        if dwp is not None:
+        if need_dw:
+            dwp = torch.empty(cout_p, 9 * cin_p, dtype=_f32, device=dev)
+            _gemm(_t16_padded(dy16), _t16_padded(col), dwp, M=cout_p)       # dW = dY^T col, split-K over the tokens
             dw = dwp.reshape(cout_p, 3, 3, cin_p).permute(0, 3, 1, 2)[:Cout, :Cin].contiguous()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dy.contiguous())[0]
@@ -275,6 +427,15 @@ def conv3x3(x, weight, bias, frames, Hi, Wi, stride=1, upsample=False):
 # ------------------------------------------------------------------------------------------------
 # Conv3d (3,1,1) of the time_stack ResBlocks: a 3-tap GEMM over the frame axis, rows (clip, t, hw)
 # ------------------------------------------------------------------------------------------------
+def _pack_t3(dt):
+    return lambda w: packing.pack_conv_t3(w, dtype=dt)
+
+
+def _pack_t3_dgrad(dt):
+    """dgrad of the (3,1,1) convolution = the same 3-tap GEMM over dY with W'[cin][kt][cout] = W[cout][cin][2-kt]."""
+    return lambda w: packing.pack_conv_t3(w.detach().permute(1, 0, 2, 3, 4).flip(2), dtype=dt)
+
+
 class ConvT3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, T, HW):
@@ -283,11 +444,12 @@ class ConvT3(torch.autograd.Function):
         Cout = weight.shape[0]
         if Cc % 32 or Cout % 32:
             raise NotImplementedError("ConvT3: channels must be multiples of 32")
-        x16 = _cast16(x)
-        w16 = PACK.get(weight, "t3", packing.pack_conv_t3)
+        dt = _dt(FWD_DTYPE)
+        x16 = _cast16(x, dt)
+        w16 = PACK.get(weight, f"t3_{FWD_DTYPE}", _pack_t3(dt))
         y = torch.empty(M, Cout, dtype=_f32, device=x.device)
-        ops.gemm(x16, w16, y, M=M, mode=GEMM_TEMPORAL3, bias=None if bias is None else bias.detach().float(),
-                 conv=dict(Cin=Cc, T=T, HW=HW))
+        _gemm(x16, w16, y, M=M, mode=GEMM_TEMPORAL3, bias=None if bias is None else bias.detach().float(),
+              conv=dict(Cin=Cc, T=T, HW=HW))
         ctx.save_for_backward(x16, weight)
         ctx.T, ctx.HW, ctx.has_bias = T, HW, bias is not None
         return y
@@ -299,22 +461,20 @@ class ConvT3(torch.autograd.Function):
         Cout = weight.shape[0]
         dev = dy.device
         dy = dy.contiguous()
-        lib = _lib.load()
-        w16 = PACK.get(weight, "t3", packing.pack_conv_t3)
-        wt16 = PACK.get(weight, "t3t", lambda w: w16.t().contiguous())            # [3C, Cout]
-        col = None
-        if ctx.needs_input_grad[1]:
-            col = torch.empty(M, 3 * Cc, dtype=_f16, device=dev)
-            check(lib.gcd_im2col_t3_f16(x16.data_ptr(), _ld(x16), col.data_ptr(), M, Cc, ctx.T, ctx.HW, _stream()),
-                  "gcd_im2col_t3_f16")
-        dcol, dwp = _grad_contractions(dy, col if col is not None else x16[:, :0], wt16,
-                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dt = _dt(GRAD_DTYPE)
+        dy16 = _cast16(dy, dt)
         dx = dw = db = None
-        if dcol is not None:
+        if ctx.needs_input_grad[0]:
+            wd = PACK.get(weight, f"t3d_{GRAD_DTYPE}", _pack_t3_dgrad(dt))          # [Cin, 3*Cout]
             dx = torch.empty(M, Cc, dtype=_f32, device=dev)
-            check(lib.gcd_col2im_t3_f32(dcol.data_ptr(), dx.data_ptr(), Cc, M, Cc, ctx.T, ctx.HW, _stream()),
-                  "gcd_col2im_t3_f32")
-        if dwp is not None:
+            _gemm(dy16, wd, dx, M=M, mode=GEMM_TEMPORAL3, conv=dict(Cin=Cout, T=ctx.T, HW=ctx.HW))
+        if ctx.needs_input_grad[1]:
+            xg = _as_dtype(x16, dt)
+            col = torch.empty(M, 3 * Cc, dtype=dt, device=dev)
+            check(_lib.load().gcd_im2col_t3_f16(xg.data_ptr(), _ld(xg), col.data_ptr(), M, Cc, ctx.T, ctx.HW,
+                                                _stream()), "gcd_im2col_t3_f16")
+            dwp = torch.empty(Cout, 3 * Cc, dtype=_f32, device=dev)
+            _gemm(_t16_padded(dy16), _t16_padded(col), dwp, M=Cout)
             dw = dwp.reshape(Cout, 3, Cc).permute(0, 2, 1).reshape(Cout, Cc, 3, 1, 1).contiguous()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum(dy)[0]
@@ -444,51 +604,20 @@ class SpatialAttention(torch.autograd.Function):
         ops.attn_transpose_v(qkv16, frames, S, heads, vt, S_pad)
         out16 = torch.empty(M, Cc, dtype=_f16, device=qkv.device)
         ops.attn_spatial(qkv16, vt, S_pad, out16, frames, S, heads, q_prescaled=False)
-        ctx.save_for_backward(qkv16)
+        ctx.save_for_backward(qkv16, out16)
         ctx.dims = (frames, S, heads)
         return out16.float()
 
     @staticmethod
     def backward(ctx, dO):
-        (qkv16,) = ctx.saved_tensors
+        """Flash-style backward on gcd_attn_spatial_bwd (attn_bwd.hip): P is recomputed tile by tile from a
+        per-query log-sum-exp, one launch sequence for all (frame, head) pairs."""
+        qkv16, out16 = ctx.saved_tensors
         frames, S, heads = ctx.dims
-        Cc = heads * 64
-        dev = dO.device
-        dO = dO.contiguous()
-        if S % 4:
-            raise NotImplementedError(f"SpatialAttention backward: {S} tokens per frame (needs a multiple of 4)")
-        dqkv = torch.empty(frames * S, 3 * Cc, dtype=_f32, device=dev)
-        lib = _lib.load()
-        # the token axis is a GEMM contraction axis here: zero-pad it to the 64-deep granule (padded
-        # keys never enter a softmax: it runs over the S x S corner only)
-        Sp = (S + 63) // 64 * 64
-        z16 = lambda *sh: torch.zeros(*sh, dtype=_f16, device=dev)      # noqa: E731
-        qp, kp, vp, dOp = z16(Sp, 64), z16(Sp, 64), z16(Sp, 64), z16(Sp, 64)
-        P, dS = z16(Sp, Sp), z16(Sp, Sp)
-        Pt, dSt = torch.empty(Sp, Sp, dtype=_f16, device=dev), torch.empty(Sp, Sp, dtype=_f16, device=dev)
-        scores = torch.empty(Sp, Sp, dtype=_f32, device=dev)
-        dP = torch.empty(Sp, Sp, dtype=_f32, device=dev)
-        kt, qt, dOt = (torch.empty(64, Sp, dtype=_f16, device=dev) for _ in range(3))
-        for f in range(frames):
-            rows = slice(f * S, (f + 1) * S)
-            for h in range(heads):
-                qp[:S] = qkv16[rows, h * 64:(h + 1) * 64]
-                kp[:S] = qkv16[rows, Cc + h * 64:Cc + (h + 1) * 64]
-                vp[:S] = qkv16[rows, 2 * Cc + h * 64:2 * Cc + (h + 1) * 64]
-                ops.cast_f16(dO[rows, h * 64:(h + 1) * 64], dOp[:S])
-                ops.gemm(qp, kp, scores, M=Sp, s_acc=0.125)
-                ops.softmax_rows(scores[:S, :S], P[:S, :S])
-                ops.transpose_f16(P, Pt)
-                ops.transpose_f16(dOp, dOt)
-                ops.gemm(Pt[:S], dOt, dqkv[rows, 2 * Cc + h * 64:2 * Cc + (h + 1) * 64], M=S)      # dV = P^T dO
-                ops.gemm(dOp, vp, dP, M=Sp)                                                           # dP = dO V^T
-                check(lib.gcd_softmax_bwd_rows(P.data_ptr(), Sp, dP.data_ptr(), Sp, dS.data_ptr(), Sp, S, S,
-                                               0.125, _stream()), "gcd_softmax_bwd_rows")
-                ops.transpose_f16(kp, kt)
-                ops.transpose_f16(qp, qt)
-                ops.transpose_f16(dS, dSt)
-                ops.gemm(dS[:S], kt, dqkv[rows, h * 64:(h + 1) * 64], M=S)                            # dQ = dS K
-                ops.gemm(dSt[:S], qt, dqkv[rows, Cc + h * 64:Cc + (h + 1) * 64], M=S)                 # dK = dS^T Q
+        dO16 = _cast16(dO.contiguous())
+        dqkv = torch.empty(frames * S, 3 * heads * 64, dtype=_f32, device=dO.device)
+        ws = _attn_ws(dO.device, ops.attn_spatial_bwd_ws_bytes(frames, S, heads))
+        ops.attn_spatial_bwd(qkv16, out16, dO16, dqkv, frames, S, heads, ws)
         return dqkv, None, None, None
 
 

@@ -26,23 +26,23 @@ __device__ __forceinline__ float max3_f(float a, float b, float c) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// V transpose: qkv[(f*S+s)*ld + 2C + h*64 + d] -> vt[((f*heads+h)*64 + d)*S_pad + perm(s)],
-// perm swaps the two middle quads of every 16-key group (see the kernel)
-// grid (S_pad/64, heads, frames), block 256
+// Per-head transpose: src[(f*S+s)*ld + col0 + h*64 + d] -> vt[((f*heads+h)*64 + d)*S_pad + perm(s)]
+// (col0 = 2C: the V third of q|k|v for the forward's P V product; the backward kernels of attn_bwd.hip
+// transpose K, Q and dO the same way), perm swaps the two middle quads of every 16-key group (see the
+// kernel).  grid (S_pad/64, heads, frames), block 256
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_transpose_v_kernel(const f16* __restrict__ qkv,
-                                                               int64_t ld, int S, int heads,
+                                                               int64_t ld, int col0, int S, int heads,
                                                                f16* __restrict__ vt, int S_pad) {
   __shared__ __attribute__((aligned(16))) f16 tile[64][72];
   const int t = threadIdx.x;
   const int s0 = blockIdx.x * 64, h = blockIdx.y, f = blockIdx.z;
-  const int C = heads * 64;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int p = i * 256 + t;
     const int tok = p >> 3, ch = p & 7;
     f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (s0 + tok < S) v = *(const f16x8*)(qkv + ((int64_t)f * S + s0 + tok) * ld + 2 * C + h * 64 + ch * 8);
+    if (s0 + tok < S) v = *(const f16x8*)(qkv + ((int64_t)f * S + s0 + tok) * ld + col0 + h * 64 + ch * 8);
     *(f16x8*)(&tile[tok][ch * 8]) = v;
   }
   __syncthreads();
@@ -68,7 +68,16 @@ extern "C" int gcd_attn_transpose_v(const void* qkv, int64_t ld, int frames, int
   GCD_CHECK_ARG(ld % 8 == 0 && ld >= 3 * heads * 64, "gcd_attn_transpose_v: ld=%lld", (long long)ld);
   GCD_CHECK_ARG(frames <= 65535 && heads <= 65535, "gcd_attn_transpose_v: grid too large");
   hipLaunchKernelGGL(attn_transpose_v_kernel, dim3(S_pad / 64, heads, frames), dim3(256), 0,
-                     (hipStream_t)stream, (const f16*)qkv, ld, S, heads, (f16*)vt, S_pad);
+                     (hipStream_t)stream, (const f16*)qkv, ld, 2 * heads * 64, S, heads, (f16*)vt, S_pad);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
+// the same transpose for any 64-wide head slice (attn_bwd.hip: K, Q of q|k|v, dO); arguments validated by the caller
+int gcd_attn_transpose_heads_launch(const f16* src, int64_t ld, int col0, int frames, int S, int heads, f16* out,
+                                    int S_pad, hipStream_t s) {
+  hipLaunchKernelGGL(attn_transpose_v_kernel, dim3(S_pad / 64, heads, frames), dim3(256), 0, s, src, ld, col0, S,
+                     heads, out, S_pad);
   GCD_CHECK_LAUNCH();
   return 0;
 }
@@ -1052,11 +1061,7 @@ extern "C" int gcd_attn_temporal_f16(const void* qkv, int64_t ld, void* out, int
   GCD_CHECK_ARG(blocks < (1ll << 31), "gcd_attn_temporal_f16: grid too large");
   const int smem = 2 * TPROB * TP_STRIDE(T);
   static GcdPerDeviceOnce attr_once;
-  if (attr_once.first_use()) {
-    GCD_CHECK_HIP(hipFuncSetAttribute((const void*)attn_temporal_kernel,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      2 * TPROB * TP_STRIDE(16)));
-  }
+  GCD_CHECK_HIP(attr_once.opt_in((const void*)attn_temporal_kernel, 2 * TPROB * TP_STRIDE(16)));
   hipLaunchKernelGGL(attn_temporal_kernel, dim3((unsigned)blocks), dim3(256), smem,
                      (hipStream_t)stream, (const f16*)qkv, ld, (f16*)out, ldo, nprob, T, HW, heads);
   GCD_CHECK_LAUNCH();

@@ -5,6 +5,9 @@
 #include <stdio.h>
 #include <stdarg.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "../../include/gcd_amd.h"
 
 typedef _Float16 f16;
@@ -44,15 +47,28 @@ void gcd_set_error(const char* fmt, ...);
 // launcher keeps one of these (static) and sets the attribute the first time it runs on each device
 // ordinal, so a process that drives several GPUs does not launch un-opted kernels on the second one.
 struct GcdPerDeviceOnce {
-  unsigned long long seen[4] = {0, 0, 0, 0};
-  bool first_use() {
+  std::atomic<unsigned long long> done[4];
+  std::mutex mu;
+  GcdPerDeviceOnce() {
+    for (auto& w : done) w.store(0, std::memory_order_relaxed);
+  }
+  // hipFuncSetAttribute(fn, MaxDynamicSharedMemorySize, bytes) once per device ordinal.  Safe for several
+  // host threads (one per GPU is the normal multi-GPU setup): the bit of a device is published only AFTER
+  // its attribute call has returned, and late arrivals wait on the mutex instead of launching early.
+  hipError_t opt_in(const void* fn, int bytes) {
     int d = 0;
-    if (hipGetDevice(&d) != hipSuccess) return true;
-    d &= 255;
+    hipError_t e = hipGetDevice(&d);
+    if (e != hipSuccess) return e;
+    if (d < 0 || d >= 256)   // beyond the table: no memo, set it every time
+      return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     const unsigned long long bit = 1ull << (d & 63);
-    const bool was = (seen[d >> 6] & bit) != 0;
-    seen[d >> 6] |= bit;
-    return !was;
+    std::atomic<unsigned long long>& w = done[d >> 6];
+    if (w.load(std::memory_order_acquire) & bit) return hipSuccess;
+    std::lock_guard<std::mutex> g(mu);
+    if (w.load(std::memory_order_relaxed) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) w.fetch_or(bit, std::memory_order_release);
+    return e;
   }
 };
 

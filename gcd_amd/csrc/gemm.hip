@@ -280,10 +280,7 @@ static int launch_gemm(const GemmK& k, hipStream_t s) {
   constexpr int smem = 2 * (BM + BN) * 128;
   static GcdPerDeviceOnce attr_once;
   auto fn = gemm_f16_kernel<BM, BN, WM, WN, MODE, BF16>;
-  if (attr_once.first_use()) {
-    GCD_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      smem));
-  }
+  GCD_CHECK_HIP(attr_once.opt_in((const void*)fn, smem));
   GemmK kk = k;
   kk.tiles_m = (k.M + BM - 1) / BM;
   kk.tiles_n = (k.N + BN - 1) / BN;
@@ -463,11 +460,19 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
     if (d->K % 64 != 0 || (d->mode != GCD_GEMM_PLAIN && d->Cin % 64 != 0)) use_pp = true;
   }
   if (d->operand_bf16) {
-    GCD_CHECK_ARG(d->mode == GCD_GEMM_PLAIN && d->out_kind == GCD_OUT_F32 && d->K % 64 == 0 && !d->ln_out16 &&
-                      !d->colstats && !d->out_blocked && !d->a_blocked,
-                  "gcd_gemm_f16: bf16 operands are implemented for PLAIN mode with fp32 output and "
-                  "K %% 64 == 0 (K=%d), without fused LayerNorm / colstats / blocked layouts", d->K);
-    use_pp = false;          // the general 128-row kernel carries the bf16 instantiations
+    GCD_CHECK_ARG(d->out_kind == GCD_OUT_F32 && !d->ln_out16 && !d->colstats && !d->out_blocked && !d->a_blocked,
+                  "gcd_gemm_f16: bf16 operands are implemented for fp32 output, without fused LayerNorm / "
+                  "colstats / blocked layouts");
+    // every mode on the ping-pong kernel; the general 128-row kernel carries PLAIN-mode bf16 instantiations
+    // only (small problems, K %% 64 == 0)
+    if (!use_pp) {
+      if (d->mode != GCD_GEMM_PLAIN || d->K % 64 != 0) {
+        GCD_CHECK_ARG(gcd_gemm_pp_supported(k, d->mode) && impl != 1 && impl != 5 && impl != 6,
+                      "gcd_gemm_f16: bf16 operands with mode %d / K=%d need the ping-pong kernel, which the "
+                      "shape or GCD_TUNE_GEMM_IMPL=%d rules out", d->mode, d->K, impl);
+        use_pp = true;
+      }
+    }
   }
   if (d->ln_out16) {
     GCD_CHECK_ARG(use_pp && d->N == 320 && d->out_kind == GCD_OUT_F32 && d->ln_gamma && d->ln_beta &&
@@ -503,16 +508,25 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
   if (const int rc = validate_geometry(d)) return rc;
 
   // split-K: few 256x320 tiles (<= 96 of 256 CUs) and a long K — the 3x3 convs of the 9x16 level
-  if (d->workspace && !d->ln_out16 && !d->colstats && !d->a_blocked && !d->operand_bf16 &&
+  if (d->workspace && !d->ln_out16 && !d->colstats && !d->a_blocked &&
       d->out_kind != GCD_OUT_GEGLU &&
       (impl == 0 || impl == 7) &&
       gcd_gemm_pp_supported(k, d->mode) && d->N >= 160 && d->N % 4 == 0) {
     const int64_t tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 319) / 320);
     int splitk = (int)(256 / tiles);
-    if (splitk > 4) splitk = 4;
-    if (tiles <= 96 && splitk >= 2 && d->K / splitk >= 1920 &&
-        d->workspace_bytes >= (int64_t)splitk * d->M * d->N * 4 && ((uintptr_t)d->workspace & 15) == 0) {
-      return gcd_gemm_pp_launch_splitk(k, d->mode, splitk, (float*)d->workspace, s);
+    if (tiles <= 32) {
+      // a handful of tiles and a very long K: the weight gradients of the fine-tune step (dW = dY^T X, the
+      // contraction runs over the tokens).  Up to 32 K slices of at least 640, as many as the scratch holds.
+      if (splitk > 32) splitk = 32;
+      while (splitk > 1 && (d->K / splitk < 640 || d->workspace_bytes < (int64_t)splitk * d->M * d->N * 4)) --splitk;
+      if (splitk >= 2 && ((uintptr_t)d->workspace & 15) == 0)
+        return gcd_gemm_pp_launch_splitk(k, d->mode, splitk, (float*)d->workspace, s);
+    } else {
+      if (splitk > 4) splitk = 4;
+      if (tiles <= 96 && splitk >= 2 && d->K / splitk >= 1920 &&
+          d->workspace_bytes >= (int64_t)splitk * d->M * d->N * 4 && ((uintptr_t)d->workspace & 15) == 0) {
+        return gcd_gemm_pp_launch_splitk(k, d->mode, splitk, (float*)d->workspace, s);
+      }
     }
   }
 

@@ -51,10 +51,14 @@ constexpr int PP_GROUP_M = 4;
 
 #define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
+typedef __bf16 pp_bf16x8 __attribute__((ext_vector_type(8)));
+
 // VAR: ablation switches for tools/gemm_bench (0 = the product kernel; any other value computes
 // WRONG results and exists only to price the parts of the loop):
 //   1 no DMA in the main loop   2 no ds_read in the loop   4 no one-barrier stagger
 //   8 no s_setprio             16 no barriers in the loop
+// VAR bit 65536: the operands are bfloat16 (gcd_gemm_desc.operand_bf16, fp32 output): the same 16-bit staging,
+// swizzle and fragment reads, v_mfma_f32_32x32x16_bf16 instead of ..._f16 — same shape and rate on gfx950.
 template <int MODE, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -319,8 +323,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 2; ++j) {
+        if constexpr ((VAR & 65536) != 0)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pp_bf16x8, wf[i]),
+                                                              __builtin_bit_cast(pp_bf16x8, af[j]), acc[i][j], 0, 0, 0);
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+      }
     if (!(VAR & 8)) __builtin_amdgcn_s_setprio(0);
   };
   bool bars_on = true;
@@ -491,10 +500,7 @@ template <int MODE, int VAR = 0>
 int launch_pp(const GemmK& k, hipStream_t s) {
   static GcdPerDeviceOnce attr_once;
   auto fn = gemm_pp_kernel<MODE, VAR>;
-  if (attr_once.first_use()) {
-    GCD_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      PP_SMEM_LAUNCH));
-  }
+  GCD_CHECK_HIP(attr_once.opt_in((const void*)fn, PP_SMEM_LAUNCH));
   GemmK kk = k;
   kk.tiles_m = (k.M + PP_BM - 1) / PP_BM;
   kk.tiles_n = (k.N + PP_BN - 1) / PP_BN;
@@ -543,14 +549,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmK p, const
   }
 }
 
-template <int MODE>
+template <int MODE, int BF = 0>
 int launch_pp_splitk(const GemmK& k, int splitk, float* ws, hipStream_t s) {
   static GcdPerDeviceOnce attr_once;
-  auto fn = gemm_pp_kernel<MODE, 16384>;
-  if (attr_once.first_use()) {
-    GCD_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      PP_SMEM_LAUNCH));
-  }
+  auto fn = gemm_pp_kernel<MODE, 16384 + BF>;
+  GCD_CHECK_HIP(attr_once.opt_in((const void*)fn, PP_SMEM_LAUNCH));
   GemmK kk = k;
   kk.tiles_m = (k.M + PP_BM - 1) / PP_BM;
   kk.tiles_n = (k.N + PP_BN - 1) / PP_BN;
@@ -579,6 +582,16 @@ int launch_pp_splitk(const GemmK& k, int splitk, float* ws, hipStream_t s) {
 }  // namespace
 
 int gcd_gemm_pp_launch_splitk(const GemmK& k, int mode, int splitk, float* ws, hipStream_t s) {
+  if (k.operand_bf16) {
+    switch (mode) {
+      case GCD_GEMM_PLAIN:
+        return launch_pp_splitk<GCD_GEMM_PLAIN, 65536>(k, splitk, ws, s);
+      case GCD_GEMM_CONV3X3:
+        return launch_pp_splitk<GCD_GEMM_CONV3X3, 65536>(k, splitk, ws, s);
+      default:
+        return launch_pp_splitk<GCD_GEMM_TEMPORAL3, 65536>(k, splitk, ws, s);
+    }
+  }
   switch (mode) {
     case GCD_GEMM_PLAIN:
       return launch_pp_splitk<GCD_GEMM_PLAIN>(k, splitk, ws, s);
@@ -635,6 +648,17 @@ int gcd_gemm_pp_launch(const GemmK& k, int mode, hipStream_t s) {
       return 2;
     }
     return persist ? launch_pp<GCD_GEMM_PLAIN, 2048 + 8192>(k, s) : launch_pp<GCD_GEMM_PLAIN, 8192>(k, s);
+  }
+  if (k.operand_bf16) {   // validated by gcd_gemm_f16: fp32 output, no colstats / LayerNorm / blocked layouts
+    switch (mode) {
+      case GCD_GEMM_PLAIN:
+        return persist ? launch_pp<GCD_GEMM_PLAIN, 2048 + 65536>(k, s) : launch_pp<GCD_GEMM_PLAIN, 65536>(k, s);
+      case GCD_GEMM_CONV3X3:
+        return persist ? launch_pp<GCD_GEMM_CONV3X3, 2048 + 65536>(k, s) : launch_pp<GCD_GEMM_CONV3X3, 65536>(k, s);
+      default:
+        return persist ? launch_pp<GCD_GEMM_TEMPORAL3, 2048 + 65536>(k, s)
+                       : launch_pp<GCD_GEMM_TEMPORAL3, 65536>(k, s);
+    }
   }
   if (k.a_blocked)    // validated by gcd_gemm_f16: PLAIN mode, no colstats / LayerNorm / split-K
     return persist ? launch_pp<GCD_GEMM_PLAIN, 2048 + 32>(k, s) : launch_pp<GCD_GEMM_PLAIN, 32>(k, s);

@@ -121,7 +121,8 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mod
          s_acc: float = 1.0, s_r1: float = 1.0, s_r2: float = 1.0, frame_alpha=None,
          rows_per_alpha: int = 1, r1_blend: bool = False, conv=None,
          alg_flops_scale: float = 1.0, ln=None, colstats=None, probe_colstats: bool = False,
-         out_blocked: bool = False, a_blocked: bool = False, operand_bf16: bool = False):
+         out_blocked: bool = False, a_blocked: bool = False, operand_bf16: bool = False,
+         workspace: Optional[torch.Tensor] = None):
     """out = epilogue(A @ W^T); see gcd_gemm_desc in include/gcd_amd.h.
 
     conv: dict(Cin, Hi, Wi, Ho, Wo, stride, upsample) for GEMM_CONV3X3 or dict(Cin, T, HW) for
@@ -177,8 +178,10 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mod
             colstats.numel() >= 2 * (M // 64) * N
         d.colstats = colstats.data_ptr()
     if _SPLITK_ON:
-        sk = _splitk_ws(a16.device)
-        d.workspace, d.workspace_bytes = sk.data_ptr(), sk.numel() * 4
+        # split-K scratch: the caller's (the fine-tune step brings a larger one for its weight gradients) or the
+        # persistent per-(device, stream) one of the inference engine
+        sk = workspace if workspace is not None else _splitk_ws(a16.device)
+        d.workspace, d.workspace_bytes = sk.data_ptr(), sk.numel() * sk.element_size()
     expect = torch.float32 if out_kind == OUT_F32 else torch.float16
     assert out.dtype == expect, f"out dtype {out.dtype} does not match out_kind {out_kind}"
     with _Timed("gemm", 2.0 * M * N * K * alg_flops_scale, M=M, N=N, K=K, mode=mode):
@@ -299,6 +302,24 @@ def attn_spatial(qkv16, vt16, S_pad: int, out16, frames: int, S: int, heads: int
                                                out16.data_ptr(), _ld(out16), frames, S, heads,
                                                int(q_prescaled), _stream()), "gcd_attn_spatial_f16")
     return out16
+
+
+def attn_spatial_bwd(qkv16, out16, dout16, dqkv32, frames: int, S: int, heads: int, ws: torch.Tensor,
+                     scale: float = 0.125):
+    """Backward of `attn_spatial` (gcd_attn_spatial_bwd): dqkv32 fp32 [frames*S, 3C]; ws: uint8 scratch of at
+    least `attn_spatial_bwd_ws_bytes(frames, S, heads)` bytes."""
+    _need_gpu(qkv16, out16, dout16, dqkv32, ws)
+    assert qkv16.dtype == out16.dtype == dout16.dtype == torch.float16 and dqkv32.dtype == torch.float32
+    with _Timed("attn_spatial_bwd", 14.0 * frames * heads * S * S * 64, S=S, frames=frames, heads=heads):
+        check(_lib.load().gcd_attn_spatial_bwd(qkv16.data_ptr(), _ld(qkv16), out16.data_ptr(), _ld(out16),
+                                               dout16.data_ptr(), _ld(dout16), dqkv32.data_ptr(), _ld(dqkv32),
+                                               ws.data_ptr(), ws.numel() * ws.element_size(), frames, S, heads,
+                                               scale, _stream()), "gcd_attn_spatial_bwd")
+    return dqkv32
+
+
+def attn_spatial_bwd_ws_bytes(frames: int, S: int, heads: int) -> int:
+    return int(_lib.load().gcd_attn_spatial_bwd_ws_bytes(frames, S, heads))
 
 
 def attn_temporal(qkv16, out16, clips: int, T: int, HW: int, heads: int):

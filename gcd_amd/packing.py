@@ -14,7 +14,8 @@ def pack_linear(w: torch.Tensor) -> torch.Tensor:
     return w.detach().to(torch.float16).contiguous()
 
 
-def pack_conv3x3(w: torch.Tensor, cin_pad: int = 0, cout_pad: int = 0) -> torch.Tensor:
+def pack_conv3x3(w: torch.Tensor, cin_pad: int = 0, cout_pad: int = 0,
+                 dtype: torch.dtype = torch.float16) -> torch.Tensor:
     """nn.Conv2d weight [Cout, Cin, 3, 3] -> fp16 [Cout(+pad), 9*Cin(+pad)], K order (kh, kw, cin).
 
     cin_pad / cout_pad (absolute sizes) zero-pad the input channels to the 64-channel K granule and
@@ -24,8 +25,8 @@ def pack_conv3x3(w: torch.Tensor, cin_pad: int = 0, cout_pad: int = 0) -> torch.
     assert (kh, kw) == (3, 3)
     cin_p = max(cin, cin_pad)
     cout_p = max(cout, cout_pad)
-    out = torch.zeros(cout_p, 3, 3, cin_p, dtype=torch.float16, device=w.device)
-    out[:cout, :, :, :cin] = w.detach().permute(0, 2, 3, 1).to(torch.float16)
+    out = torch.zeros(cout_p, 3, 3, cin_p, dtype=dtype, device=w.device)
+    out[:cout, :, :, :cin] = w.detach().permute(0, 2, 3, 1).to(dtype)
     return out.reshape(cout_p, 9 * cin_p).contiguous()
 
 
@@ -34,12 +35,11 @@ def pack_conv1x1(w: torch.Tensor) -> torch.Tensor:
     return w.detach().reshape(w.shape[0], w.shape[1]).to(torch.float16).contiguous()
 
 
-def pack_conv_t3(w: torch.Tensor) -> torch.Tensor:
+def pack_conv_t3(w: torch.Tensor, dtype: torch.dtype = torch.float16) -> torch.Tensor:
     """nn.Conv3d (3,1,1) weight [Cout, Cin, 3, 1, 1] -> fp16 [Cout, 3*Cin], K order (kt, cin)."""
     cout, cin, kt, kh, kw = w.shape
     assert (kt, kh, kw) == (3, 1, 1)
-    return w.detach().reshape(cout, cin, 3).permute(0, 2, 1).reshape(cout, 3 * cin).to(
-        torch.float16).contiguous()
+    return w.detach().reshape(cout, cin, 3).permute(0, 2, 1).reshape(cout, 3 * cin).to(dtype).contiguous()
 
 
 def pack_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, q_scale: float = 1.0) -> torch.Tensor:

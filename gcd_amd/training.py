@@ -121,8 +121,7 @@ def _video_resblock(rb: VideoResBlock, x, emb, frames, T, H, W, ioi):
 
 
 def _self_attention(att, x, kind, dims):
-    qkv_w = torch.cat([att.to_q.weight, att.to_k.weight, att.to_v.weight], 0)
-    qkv = A.linear(x, qkv_w, None)
+    qkv = A.qkv_linear(x, att.to_q.weight, att.to_k.weight, att.to_v.weight)
     if kind == "spatial":
         o = A.spatial_attention(qkv, *dims)
     else:
@@ -184,6 +183,7 @@ def unet_forward_train(unet: VideoUNet, x: torch.Tensor, timesteps: torch.Tensor
     SpatialVideoTransformer): only block inputs are kept, the block is re-run on HIP kernels during the
     backward pass.  Gradients equal the un-checkpointed run's up to the summation order of atomics."""
     ops._need_gpu(x, timesteps, context, y)
+    A.PACK.attach(unet)          # packed operand forms are cached for registered parameters only
     T = num_video_frames
     N, _, H, W = x.shape
     assert N % T == 0 and context.dim() == 3
@@ -369,6 +369,7 @@ class AdamHIP:
         self.state = [(torch.zeros_like(p, dtype=torch.float32), torch.zeros_like(p, dtype=torch.float32))
                       for p in self.params]
         self.step_count = 0
+        self._touched = {}       # id(p) -> the moments of p have been written at least once
 
     def zero_grad(self):
         for p in self.params:
@@ -379,8 +380,16 @@ class AdamHIP:
         self.step_count += 1
         for p, (m, v) in zip(self.params, self.state):
             if p.grad is None:
-                continue
-            g = p.grad.detach().float().contiguous()
+                # A trainable parameter the graph never reached (attn2.to_q / to_k / norm2 behind the one-key
+                # cross-attention identity): torch.autograd gives the reference exact ZERO gradients there and
+                # torch.optim.Adam still steps them, which matters as soon as weight_decay != 0.  With no
+                # decay and untouched moments the update is exactly zero and is skipped.
+                if self.weight_decay == 0.0 and not self._touched.get(id(p), False):
+                    continue
+                g = torch.zeros_like(p, dtype=torch.float32)
+            else:
+                g = p.grad.detach().float().contiguous()
+            self._touched[id(p)] = True
             A.adam_step(p.data, g, m, v, self.step_count, self.lr, self.betas, self.eps, self.weight_decay,
                         grad_scale)
         # gcd_adam_step writes the parameters through raw pointers, which torch's version counters do
@@ -393,11 +402,22 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], dist=None, group=N
     """Average the gradients over the data-parallel ranks (what Lightning's DDPStrategy does for the
     reference, main.py:826-843): flat fp32 buckets of ~`bucket_bytes` (large, few: xGMI ring
     all-reduce is per-link bound), one asynchronous all-reduce each, results copied back
-    divided by the world size.  Returns the number of buckets.  No-op for a single process."""
+    divided by the world size.  Returns the number of buckets.  No-op for a single process.
+
+    Buckets run over EVERY trainable parameter in the order given, a missing gradient entering as zeros (and
+    coming back as the mean of the other ranks' — zero if nobody had one): the bucket layout is then the
+    same on every rank even when ranks disagree on which parameters their graph reached, which would
+    otherwise hang the collective."""
     if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return 0
     world = dist.get_world_size(group)
-    grads = [p.grad for p in params if p.requires_grad and p.grad is not None]
+    grads = []
+    for p in params:
+        if not p.requires_grad:
+            continue
+        if p.grad is None:
+            p.grad = torch.zeros_like(p, dtype=torch.float32)
+        grads.append(p.grad)
     buckets: List[List[torch.Tensor]] = [[]]
     size = 0
     for g in grads:

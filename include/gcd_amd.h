@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GCD_AMD_ABI_VERSION 4
+#define GCD_AMD_ABI_VERSION 5
 
 /* ---- library ------------------------------------------------------------------------------ */
 int gcd_abi_version(void);
@@ -318,6 +318,15 @@ int gcd_geglu_bwd_f32(const float* h, int64_t ldh, const float* dout, int64_t ld
 /* Softmax backward over R rows of S scores: dS16 = P16 * (dP - rowsum(P16*dP)) * scale.              */
 int gcd_softmax_bwd_rows(const void* P16, int64_t ldp, const float* dP, int64_t lddp, void* dS16,
                          int64_t ldds, int64_t R, int S, float scale, void* stream);
+/* Backward of gcd_attn_spatial_f16 (flash style: no S x S tensor in memory; reference: torch.autograd through
+ * F.scaled_dot_product_attention, attention.py:331-335).  qkv16 / out16: what the forward consumed and produced
+ * (fp16 [frames*S, 3C] / [frames*S, C]), dout16: the incoming gradient rounded to fp16 [frames*S, C], dqkv32:
+ * fp32 [frames*S, 3C] (every element written), scale: the softmax scale (1/8).  ws: scratch of
+ * gcd_attn_spatial_bwd_ws_bytes(frames, S, heads) bytes (transposed operands, log-sum-exp and delta rows). */
+int64_t gcd_attn_spatial_bwd_ws_bytes(int frames, int S, int heads);
+int gcd_attn_spatial_bwd(const void* qkv16, int64_t ld, const void* out16, int64_t ldo, const void* dout16,
+                         int64_t lddo, void* dqkv32, int64_t ldg, void* ws, int64_t ws_bytes, int frames, int S,
+                         int heads, float scale, void* stream);
 /* Backward of gcd_attn_temporal_f16 (T <= 16 tokens, d = 64): dqkv fp32 [M, 3C] from dO fp32 [M, C].  */
 int gcd_attn_temporal_bwd(const void* qkv16, int64_t ld, const float* dO, int64_t lddo, float* dqkv,
                           int64_t lddq, int clips, int T, int HW, int heads, void* stream);

@@ -46,8 +46,10 @@ def _check(name, got, ref, tol=TOL_OP):
 
 
 # ------------------------------------------------------------------------------------------ operators
-@pytest.mark.parametrize("M,K,N,bias", [(300, 64, 128, True), (28, 256, 64, True), (1000, 320, 48, False)])
+@pytest.mark.parametrize("M,K,N,bias", [(300, 64, 128, True), (28, 256, 64, True), (1000, 320, 48, False),
+                                        (43008, 320, 960, False), (10752, 640, 5120, True)])
 def test_linear_backward(gpu, M, K, N, bias):
+    """(the last two: cfg4's token counts — dW is a 4- / 40-tile GEMM over 43008 / 10752 tokens, split-K)"""
     from gcd_amd import autograd_ops as A
     g = _gen(1)
     x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
@@ -162,7 +164,8 @@ def test_geglu_backward(gpu):
     _check("dh", hg.grad, hr.grad, 1e-5)
 
 
-@pytest.mark.parametrize("frames,S,heads", [(2, 64, 2), (1, 128, 1), (2, 16, 1), (1, 100, 2)])
+@pytest.mark.parametrize("frames,S,heads", [(2, 64, 2), (1, 128, 1), (2, 16, 1), (1, 100, 2), (3, 24, 4), (1, 33, 1),
+                                            (2, 201, 1), (2, 1536, 2)])
 def test_spatial_attention_backward(gpu, frames, S, heads):
     from gcd_amd import autograd_ops as A
     g = _gen(7)
@@ -178,6 +181,29 @@ def test_spatial_attention_backward(gpu, frames, S, heads):
     _check("out", y, yr, 1.5e-3)
     y.backward(dO.to(gpu))
     _check("dqkv", qg.grad, qr.grad)
+
+
+def test_spatial_attention_backward_small_gradients_and_scale(gpu):
+    """The flash backward against fp64 math on the SAME fp16-rounded q | k | v, O and dO it consumes: isolates
+    the kernels' own error (P and dS rounded to fp16 for the MFMAs) from the rounding of the inputs; with
+    row-dependent magnitudes so that a wrong lse / delta row mapping cannot hide."""
+    from gcd_amd import ops
+    g = _gen(71)
+    frames, S, heads = 2, 300, 3
+    C = heads * 64
+    qkv = (torch.randn(frames * S, 3 * C, generator=g) * torch.linspace(0.3, 2.0, frames * S)[:, None]).half()
+    dO = (torch.randn(frames * S, C, generator=g) * torch.linspace(2.0, 0.1, frames * S)[:, None]).half()
+    q, k, v = (t.double().reshape(frames, S, heads, 64).transpose(1, 2).requires_grad_(True) for t in qkv.chunk(3, dim=-1))
+    o = F.scaled_dot_product_attention(q, k, v)
+    o16 = o.detach().transpose(1, 2).reshape(frames * S, C).half()
+    # delta uses the fp16 O the forward produced: feed the same here
+    o.backward(dO.double().reshape(frames, S, heads, 64).transpose(1, 2))
+    ref = torch.cat([t.grad.transpose(1, 2).reshape(frames * S, C) for t in (q, k, v)], 1)
+    dqkv = torch.empty(frames * S, 3 * C, device=gpu)
+    ws = torch.empty(ops.attn_spatial_bwd_ws_bytes(frames, S, heads), dtype=torch.uint8, device=gpu)
+    ops.attn_spatial_bwd(qkv.to(gpu), o16.to(gpu), dO.to(gpu), dqkv, frames, S, heads, ws)
+    for i, name in enumerate("qkv"):
+        _check("d" + name, dqkv[:, i * C:(i + 1) * C], ref[:, i * C:(i + 1) * C], 1e-3)
 
 
 @pytest.mark.parametrize("clips,T,HW,heads", [(2, 14, 6, 2), (1, 4, 33, 1), (1, 16, 5, 3)])
@@ -218,6 +244,24 @@ def test_adam_step_vs_torch(gpu):
         opt_m.step(grad_scale=1.0 / 64.0)
     for p, q in zip(ref, mine):
         assert rel_l2(q, p) < 1e-6
+
+
+def test_qkv_linear_backward(gpu):
+    from gcd_amd import autograd_ops as A
+    g = _gen(41)
+    M, C = 700, 128
+    x = torch.randn(M, C, generator=g)
+    ws = [torch.randn(C, C, generator=g) / math.sqrt(C) for _ in range(3)]
+    dy = torch.randn(M, 3 * C, generator=g)
+    xr, wr = _leaf(x), [_leaf(w) for w in ws]
+    F.linear(xr, torch.cat(wr, 0)).backward(dy)
+    xg, wg = _leaf(x, gpu), [_leaf(w, gpu) for w in ws]
+    y = A.qkv_linear(xg, *wg)
+    _check("y", y, F.linear(x, torch.cat(ws, 0)))
+    y.backward(dy.to(gpu))
+    _check("dx", xg.grad, xr.grad)
+    for a, b, n in zip(wg, wr, "qkv"):
+        _check("dw" + n, a.grad, b.grad)
 
 
 # -------------------------------------------------------------------------------------- blocks, network
@@ -420,6 +464,103 @@ def test_activation_checkpointing_matches(gpu):
         assert rel_l2(grads[1][n], grads[0][n]) < 1e-5, n
     print(f"activations held after forward: {held[0] / 2**20:.0f} MiB plain, {held[1] / 2**20:.0f} MiB checkpointed")
     assert held[1] < 0.5 * held[0]
+
+
+@pytest.mark.parametrize("mode", ["no_grad", "frozen"])
+def test_pack_cache_never_serves_a_recycled_temporary(gpu, mode):
+    """the packed-operand cache was keyed on (address, shape, version) of whatever tensor it was
+    handed; the q | k | v weight used to be a torch.cat temporary, which under no_grad / with frozen weights is
+    a leaf whose address the allocator recycles for the NEXT block's temporary — which then ran with the
+    previous block's weights.  Two consecutive self-attentions with different weights, evaluated repeatedly."""
+    from gcd_amd import autograd_ops as A
+    from gcd_amd import training as TR
+    net, sd = _tiny_unet(gpu)
+    A.PACK.clear()
+    A.PACK.attach(net)
+    atts = [net.input_blocks[1][1].transformer_blocks[0].attn1, net.input_blocks[2][1].transformer_blocks[0].attn1]
+    frames, S, heads = 2, 64, atts[0].heads
+    C = heads * 64
+    g = _gen(51)
+    x = torch.randn(frames * S, C, generator=g)
+
+    def ref(att):
+        w = {n: p.detach().cpu() for n, p in att.named_parameters()}
+        q, k, v = (F.linear(x, w[f"to_{n}.weight"]).reshape(frames, S, heads, 64).transpose(1, 2) for n in "qkv")
+        o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(frames * S, C)
+        return F.linear(o, w["to_out.0.weight"], w["to_out.0.bias"])
+
+    if mode == "frozen":
+        for a in atts:
+            for p in a.parameters():
+                p.requires_grad_(False)
+    xg = x.to(gpu)
+    for rep in range(3):
+        for i, a in enumerate(atts):
+            if mode == "no_grad":
+                with torch.no_grad():
+                    y = TR._self_attention(a, xg, "spatial", (frames, S, heads))
+            else:
+                y = TR._self_attention(a, xg, "spatial", (frames, S, heads))
+            _check(f"rep {rep} block {i}", y, ref(a), 2e-3)
+    # and a temporary handed to the cache is packed, never kept
+    t = torch.randn(64, 64, device=gpu)
+    n0 = len(A.PACK._d)
+    A.PACK.get(t, "lin_fp16", lambda w: w.half())
+    assert len(A.PACK._d) == n0
+
+
+def test_bf16_operands_forward_and_backward(gpu):
+    """`set_train_dtype("bf16")` (BASELINE.json cfg4 names bf16): every GEMM-family contraction, forward and
+    backward, on bfloat16 operands — v_mfma_f32_32x32x16_bf16 on the ping-pong kernel for all three modes —
+    against fp32 torch; tolerance is bf16's (8 significant bits per operand)."""
+    from gcd_amd import autograd_ops as A
+    A.set_train_dtype("bf16")
+    try:
+        g = _gen(61)
+        for (M, K, N) in [(2048, 320, 640), (43008, 320, 320)]:
+            x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+            dy = torch.randn(M, N, generator=g)
+            xr, wr, br = _leaf(x), _leaf(w), _leaf(b)
+            yr = F.linear(xr, wr, br)
+            yr.backward(dy)
+            xg, wg, bg = _leaf(x, gpu), _leaf(w, gpu), _leaf(b, gpu)
+            y = A.linear(xg, wg, bg)
+            print(f"Linear {M}x{K}x{N}, bf16 operands:")
+            _check("y", y, yr, 8e-3)
+            y.backward(dy.to(gpu))
+            _check("dx", xg.grad, xr.grad, 8e-3)
+            _check("dw", wg.grad, wr.grad, 8e-3)
+        frames, H, W, C = 4, 16, 16, 320          # 1024 tokens x 320: full ping-pong tiles
+        x = torch.randn(frames, C, H, W, generator=g)
+        w = torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C)
+        xr, wr = _leaf(x), _leaf(w)
+        yr = F.conv2d(xr, wr, None, padding=1)
+        dy = torch.randn(yr.shape, generator=g)
+        yr.backward(dy)
+        xg, wg = _leaf(_tok(x), gpu), _leaf(w, gpu)
+        y = A.conv3x3(xg, wg, None, frames, H, W)
+        print("Conv3x3, bf16 operands:")
+        _check("y", y, _tok(yr), 8e-3)
+        y.backward(_tok(dy).to(gpu))
+        _check("dx", xg.grad, _tok(xr.grad), 8e-3)
+        _check("dw", wg.grad, wr.grad, 8e-3)
+        clips, T, HW = 2, 14, 64
+        x = torch.randn(clips, C, T, HW, 1, generator=g)
+        w = torch.randn(C, C, 3, 1, 1, generator=g) / math.sqrt(3 * C)
+        xr, wr = _leaf(x), _leaf(w)
+        yr = F.conv3d(xr, wr, None, padding=(1, 0, 0))
+        dy = torch.randn(yr.shape, generator=g)
+        yr.backward(dy)
+        tok = lambda t: t[..., 0].permute(0, 2, 3, 1).reshape(clips * T * HW, C).contiguous()   # noqa: E731
+        xg, wg = _leaf(tok(x), gpu), _leaf(w, gpu)
+        y = A.conv_t3(xg, wg, None, T, HW)
+        print("Conv (3,1,1), bf16 operands:")
+        _check("y", y, tok(yr), 8e-3)
+        y.backward(tok(dy).to(gpu))
+        _check("dx", xg.grad, tok(xr.grad), 8e-3)
+        _check("dw", wg.grad, wr.grad, 8e-3)
+    finally:
+        A.set_train_dtype("fp16")
 
 
 def test_bf16_gradient_contractions(gpu):

@@ -19,12 +19,12 @@ GOLD = ROOT / "tests" / "golden"
 def test_library_exports_every_declared_symbol():
     from gcd_amd import _lib
     header = (ROOT / "include" / "gcd_amd.h").read_text()
-    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(gcd_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(gcd_\w+)\s*\(", header, flags=re.M))
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     lib = _lib.load()                       # raises if the .so has not been built
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.gcd_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.gcd_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_gemm_desc_layout_matches_header(tmp_path):

@@ -1,27 +1,13 @@
 """CPU, world_size 2 over gloo: the clip sharding + all-gather that bench.py / inference use on RCCL."""
-import os
-import socket
-
 import pytest
 import torch
 import torch.distributed as dist
-import torch.multiprocessing as mp
-
 from gcd_amd import parallel
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+from gloo_util import init as _init, run_world as _run_world
 
 
 def _worker(rank, world, port, num_clips, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init(rank, world, port)
     try:
         mine = parallel.clips_for_rank(num_clips, rank, world)
         # "denoise" each clip: a deterministic function of the clip id
@@ -38,17 +24,7 @@ def _worker(rank, world, port, num_clips, q):
 
 @pytest.mark.parametrize("num_clips", [2, 5])
 def test_gloo_world2_gather(num_clips):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, num_clips, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    res = dict(q.get(timeout=10) for _ in range(2))
-    assert res == {0: True, 1: True}
+    assert _run_world(_worker, 2, num_clips) == {0: True, 1: True}
 
 
 def test_clip_assignment_covers_everything():
@@ -99,9 +75,7 @@ def _sample_all(num_clips, dist_mod):
 
 
 def _sample_worker(rank, world, port, num_clips, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init(rank, world, port)
     try:
         got = _sample_all(num_clips, dist)
         q.put((rank, [t.clone() for t in got]))
@@ -114,16 +88,7 @@ def test_sample_clips_world2_equals_single_process(num_clips):
     """1 clip: rank 1 holds nothing (the empty-rank pad must match dtype / device); 5 clips: ragged."""
     want = _sample_all(num_clips, None)
     assert len(want) == num_clips and all(t.shape == (14, 4, 6, 8) for t in want)
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_sample_worker, args=(r, 2, port, num_clips, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = dict(q.get(timeout=120) for _ in range(2))
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    res = _run_world(_sample_worker, 2, num_clips)
     for r in (0, 1):
         assert len(res[r]) == num_clips
         for a, b in zip(res[r], want):
