@@ -240,91 +240,21 @@ PACK = _PackCache()
 
 
 # ------------------------------------------------------------------------------------------------
-# Linear:  y = x @ W^T + b            (attention.py q/k/v/out, FeedForward, proj_in/out, emb MLPs)
+# The contractions.  Each has a forward and a backward helper on an already-prepared 16-bit activation
+# `a16`; `Fused` below turns  [norm ->] contraction [+ per-frame vector] [+ residual]  into ONE graph node.
+#   lin   y = a @ W^T + b                 (attention.py q/k/v/out, FeedForward, proj_in/out, emb MLPs)
+#   qkv   q|k|v = a @ [Wq; Wk; Wv]^T      (one GEMM; attention.py:281-296 runs three)
+#   c3    Conv2d 3x3 as implicit GEMM over token-major activations (stride 1 / 2, fused x2 upsample)
+#   t3    Conv3d (3,1,1) of the time_stack ResBlocks: a 3-tap GEMM over the frame axis
 # ------------------------------------------------------------------------------------------------
 def _pack_lin(dt):
-    return lambda w: w.detach().to(dt).contiguous()
+    return lambda w: w.detach().reshape(w.shape[0], -1).to(dt).contiguous()
 
 
 def _pack_lin_t(dt):
-    return lambda w: w.detach().t().to(dt).contiguous()      # [K, N], one rounding from the fp32 parameter
+    return lambda w: w.detach().reshape(w.shape[0], -1).t().to(dt).contiguous()   # [K, N], one rounding from fp32
 
 
-class Linear16(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, weight, bias):
-        ops._need_gpu(x, weight)
-        M, K = x.shape
-        N = weight.shape[0]
-        if K % 32 or N % 16:
-            raise NotImplementedError(f"Linear16: K={K} must be a multiple of 32 and N={N} of 16")
-        dt = _dt(FWD_DTYPE)
-        x16 = _cast16(x, dt)
-        w16 = PACK.get(weight, f"lin_{FWD_DTYPE}", _pack_lin(dt))
-        y = torch.empty(M, N, dtype=_f32, device=x.device)
-        _gemm(x16, w16, y, M=M, bias=None if bias is None else bias.detach().float())
-        ctx.save_for_backward(x16, weight)
-        ctx.has_bias = bias is not None
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x16, weight = ctx.saved_tensors
-        dy = dy.contiguous()
-        db = None
-        dx, dw = _grad_contractions(dy, x16, lambda dt: PACK.get(weight, f"lin_t_{dt}", _pack_lin_t(dt)),
-                                    ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy)[0]
-        return dx, dw, db
-
-
-def linear(x, weight, bias=None):
-    return Linear16.apply(x, weight, bias)
-
-
-class QKVLinear16(torch.autograd.Function):
-    """q | k | v = x @ [Wq; Wk; Wv]^T as ONE GEMM (attention.py:281-296 runs three).  The concatenated operand
-    is packed from the three parameters and cached on all three (PACK.get_multi) — there is no concatenated
-    weight tensor in the graph whose storage could be recycled."""
-
-    @staticmethod
-    def forward(ctx, x, wq, wk, wv):
-        ops._need_gpu(x, wq)
-        M, K = x.shape
-        dt = _dt(FWD_DTYPE)
-        x16 = _cast16(x, dt)
-        w16 = PACK.get_multi((wq, wk, wv), f"qkv_{FWD_DTYPE}",
-                             lambda ws: torch.cat([w.to(dt) for w in ws], 0).contiguous())
-        y = torch.empty(M, w16.shape[0], dtype=_f32, device=x.device)
-        _gemm(x16, w16, y, M=M)
-        ctx.save_for_backward(x16, wq, wk, wv)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x16, wq, wk, wv = ctx.saved_tensors
-        dy = dy.contiguous()
-        need_dw = any(ctx.needs_input_grad[1:4])
-        dx, dw = _grad_contractions(
-            dy, x16,
-            lambda dt: PACK.get_multi((wq, wk, wv), f"qkv_t_{dt}",
-                                      lambda ws: torch.cat([w.t().to(dt) for w in ws], 1).contiguous()),
-            ctx.needs_input_grad[0], need_dw)
-        dq = dk = dv = None
-        if dw is not None:
-            n = wq.shape[0]
-            dq, dk, dv = dw[:n], dw[n:2 * n], dw[2 * n:]
-        return dx, dq, dk, dv
-
-
-def qkv_linear(x, wq, wk, wv):
-    return QKVLinear16.apply(x, wq, wk, wv)
-
-
-# ------------------------------------------------------------------------------------------------
-# Conv2d 3x3 as implicit GEMM over token-major activations (stride 1 / 2, fused x2 nearest upsample)
-# ------------------------------------------------------------------------------------------------
 def _pack_c3(dt, cin_p, cout_p):
     return lambda w: packing.pack_conv3x3(w, cin_pad=cin_p, cout_pad=cout_p, dtype=dt)
 
@@ -336,97 +266,6 @@ def _pack_c3_dgrad(dt, cin_p, cout_p):
                                           cout_pad=cin_p, dtype=dt)
 
 
-class Conv3x3(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, weight, bias, frames, Hi, Wi, stride, upsample):
-        ops._need_gpu(x, weight)
-        Cout, Cin = weight.shape[0], weight.shape[1]
-        cin_p = (Cin + 63) // 64 * 64 if Cin % 32 else Cin          # first conv: 8 -> 64 channels
-        cout_p = (Cout + 31) // 32 * 32 if Cout % 32 else Cout      # last conv: 4 -> 32 channels
-        if upsample:
-            Ho, Wo = 2 * Hi, 2 * Wi
-        else:
-            Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
-        Min, Mout = frames * Hi * Wi, frames * Ho * Wo
-        assert x.shape == (Min, Cin)
-        dt = _dt(FWD_DTYPE)
-        if cin_p != Cin:
-            x16 = torch.zeros(Min, cin_p, dtype=dt, device=x.device)
-            _cast16_into(x, x16[:, :Cin])
-        else:
-            x16 = _cast16(x, dt)
-        w16 = PACK.get(weight, f"c3_{cin_p}_{cout_p}_{FWD_DTYPE}", _pack_c3(dt, cin_p, cout_p))
-        b = None
-        if bias is not None:
-            b = torch.zeros(cout_p, dtype=_f32, device=x.device)
-            b[:Cout] = bias.detach().float()
-        y = torch.empty(Mout, cout_p, dtype=_f32, device=x.device)
-        geo = dict(Cin=cin_p, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo, stride=stride, upsample=int(upsample))
-        _gemm(x16, w16, y, M=Mout, mode=GEMM_CONV3X3, bias=b, conv=geo)
-        ctx.save_for_backward(x16, weight)
-        ctx.geo, ctx.frames, ctx.dims = geo, frames, (Cin, Cout, cin_p, cout_p)
-        ctx.has_bias = bias is not None
-        return y[:, :Cout] if cout_p != Cout else y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x16, weight = ctx.saved_tensors
-        Cin, Cout, cin_p, cout_p = ctx.dims
-        geo, frames = ctx.geo, ctx.frames
-        Hi, Wi, Ho, Wo = geo["Hi"], geo["Wi"], geo["Ho"], geo["Wo"]
-        Mout, Min = frames * Ho * Wo, frames * Hi * Wi
-        dev = dy.device
-        dyp = dy.contiguous()
-        if cout_p != Cout:
-            dyp = torch.zeros(Mout, cout_p, dtype=_f32, device=dev)
-            dyp[:, :Cout] = dy
-        lib = _lib.load()
-        dt = _dt(GRAD_DTYPE)
-        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        dx = dw = db = None
-        dy16 = _cast16(dyp, dt)
-        if need_dx and geo["stride"] == 1:
-            # dgrad as an implicit-GEMM convolution of dY on the forward kernel (no dcol tensor, no col2im):
-            # at the output resolution; a fused x2 upsample then sums every 2 x 2 block back onto its source
-            wd = PACK.get(weight, f"c3d_{cin_p}_{cout_p}_{GRAD_DTYPE}", _pack_c3_dgrad(dt, cin_p, cout_p))
-            dxo = torch.empty(Mout, cin_p, dtype=_f32, device=dev)
-            _gemm(dy16, wd, dxo, M=Mout, mode=GEMM_CONV3X3,
-                  conv=dict(Cin=cout_p, Hi=Ho, Wi=Wo, Ho=Ho, Wo=Wo, stride=1, upsample=0))
-            if geo["upsample"]:
-                dxo = dxo.reshape(frames, Hi, 2, Wi, 2, cin_p).sum(dim=(2, 4)).reshape(Min, cin_p)
-            dx = dxo[:, :Cin] if cin_p != Cin else dxo
-        col = None
-        if need_dw or (need_dx and dx is None):
-            xg = _as_dtype(x16, dt)
-            col = torch.empty(Mout, 9 * cin_p, dtype=dt, device=dev)
-            check(lib.gcd_im2col3x3_f16(xg.data_ptr(), _ld(xg), col.data_ptr(), frames, cin_p, Hi, Wi, Ho, Wo,
-                                        geo["stride"], geo["upsample"], 0, _stream()), "gcd_im2col3x3_f16")
-        if need_dx and dx is None:
-            # stride 2 (the three Downsample convs): dcol = dY W by a plain GEMM, then the col2im gather
-            wt = PACK.get(weight, f"c3t_{cin_p}_{cout_p}_{GRAD_DTYPE}",
-                          lambda w: _pack_c3(dt, cin_p, cout_p)(w).t().contiguous())      # [9*cin_p, cout_p]
-            dcol = torch.empty(Mout, 9 * cin_p, dtype=_f32, device=dev)
-            _gemm(dy16, wt, dcol, M=Mout)
-            dxp = torch.empty(Min, cin_p, dtype=_f32, device=dev)
-            check(lib.gcd_col2im3x3_f32(dcol.data_ptr(), dxp.data_ptr(), cin_p, frames, cin_p, Hi, Wi, Ho, Wo,
-                                        geo["stride"], geo["upsample"], 0, _stream()), "gcd_col2im3x3_f32")
-            dx = dxp[:, :Cin] if cin_p != Cin else dxp
-        if need_dw:
-            dwp = torch.empty(cout_p, 9 * cin_p, dtype=_f32, device=dev)
-            _gemm(_t16_padded(dy16), _t16_padded(col), dwp, M=cout_p)       # dW = dY^T col, split-K over the tokens
-            dw = dwp.reshape(cout_p, 3, 3, cin_p).permute(0, 3, 1, 2)[:Cout, :Cin].contiguous()
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy.contiguous())[0]
-        return dx, dw, db, None, None, None, None, None
-
-
-def conv3x3(x, weight, bias, frames, Hi, Wi, stride=1, upsample=False):
-    return Conv3x3.apply(x, weight, bias, frames, Hi, Wi, stride, upsample)
-
-
-# ------------------------------------------------------------------------------------------------
-# Conv3d (3,1,1) of the time_stack ResBlocks: a 3-tap GEMM over the frame axis, rows (clip, t, hw)
-# ------------------------------------------------------------------------------------------------
 def _pack_t3(dt):
     return lambda w: packing.pack_conv_t3(w, dtype=dt)
 
@@ -436,53 +275,319 @@ def _pack_t3_dgrad(dt):
     return lambda w: packing.pack_conv_t3(w.detach().permute(1, 0, 2, 3, 4).flip(2), dtype=dt)
 
 
-class ConvT3(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, weight, bias, T, HW):
-        ops._need_gpu(x, weight)
-        M, Cc = x.shape
+def _epi(bias, rowvec, residual):
+    kw = {}
+    if bias is not None:
+        kw["bias"] = bias.detach().float()
+    if rowvec is not None:
+        v, rows = rowvec
+        kw["rowvec"], kw["rows_per_vec"] = v.detach().float().contiguous(), rows
+    if residual is not None:
+        kw["r1"] = residual.detach().contiguous()
+    return kw
+
+
+def _c3_dims(weight, geo):
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    cin_p = (Cin + 63) // 64 * 64 if Cin % 32 else Cin          # first conv: 8 -> 64 channels
+    cout_p = (Cout + 31) // 32 * 32 if Cout % 32 else Cout      # last conv: 4 -> 32 channels
+    return Cin, Cout, cin_p, cout_p
+
+
+def _contract_fwd(kind, a16, params, geo, bias_vec_res):
+    """-> y fp32 [Mout, N]"""
+    dev = a16.device
+    if kind == "lin":
+        weight, bias = params
+        M, K = a16.shape
+        N = weight.shape[0]
+        if K % 32 or N % 16:
+            raise NotImplementedError(f"linear: K={K} must be a multiple of 32 and N={N} of 16")
+        w16 = PACK.get(weight, f"lin_{a16.dtype}", _pack_lin(a16.dtype))
+        y = torch.empty(M, N, dtype=_f32, device=dev)
+        _gemm(a16, w16, y, M=M, **bias_vec_res)
+        return y
+    if kind == "qkv":
+        M = a16.shape[0]
+        dt = a16.dtype
+        w16 = PACK.get_multi(params, f"qkv_{dt}", lambda ws: torch.cat([w.to(dt) for w in ws], 0).contiguous())
+        y = torch.empty(M, w16.shape[0], dtype=_f32, device=dev)
+        _gemm(a16, w16, y, M=M, **bias_vec_res)
+        return y
+    if kind == "c3":
+        weight, bias = params
+        Cin, Cout, cin_p, cout_p = _c3_dims(weight, geo)
+        frames, Ho, Wo = geo["frames"], geo["Ho"], geo["Wo"]
+        Mout = frames * Ho * Wo
+        w16 = PACK.get(weight, f"c3_{cin_p}_{cout_p}_{a16.dtype}", _pack_c3(a16.dtype, cin_p, cout_p))
+        kw = dict(bias_vec_res)
+        if cout_p != Cout:
+            assert "r1" not in kw and "rowvec" not in kw
+            if bias is not None:
+                b = torch.zeros(cout_p, dtype=_f32, device=dev)
+                b[:Cout] = bias.detach().float()
+                kw["bias"] = b
+        y = torch.empty(Mout, cout_p, dtype=_f32, device=dev)
+        _gemm(a16, w16, y, M=Mout, mode=GEMM_CONV3X3, conv=dict(
+            Cin=cin_p, Hi=geo["Hi"], Wi=geo["Wi"], Ho=Ho, Wo=Wo, stride=geo["stride"], upsample=geo["upsample"]), **kw)
+        return y[:, :Cout] if cout_p != Cout else y
+    if kind == "t3":
+        weight, bias = params
+        M, Cc = a16.shape
         Cout = weight.shape[0]
         if Cc % 32 or Cout % 32:
-            raise NotImplementedError("ConvT3: channels must be multiples of 32")
+            raise NotImplementedError("conv_t3: channels must be multiples of 32")
+        w16 = PACK.get(weight, f"t3_{a16.dtype}", _pack_t3(a16.dtype))
+        y = torch.empty(M, Cout, dtype=_f32, device=dev)
+        _gemm(a16, w16, y, M=M, mode=GEMM_TEMPORAL3, conv=dict(Cin=Cc, T=geo["T"], HW=geo["HW"]), **bias_vec_res)
+        return y
+    raise ValueError(kind)
+
+
+def _contract_bwd(kind, dy, a16, params, geo, need_da, need_dw):
+    """dy fp32 contiguous -> (da fp32 | None, [parameter gradients in the order of `params`, bias included])."""
+    dev = dy.device
+    dt = _dt(GRAD_DTYPE)
+    lib = _lib.load()
+    if kind == "lin":
+        weight, bias = params
+        da, dw = _grad_contractions(dy, a16, lambda d: PACK.get(weight, f"lin_t_{d}", _pack_lin_t(d)),
+                                    need_da, need_dw[0])
+        if dw is not None:
+            dw = dw.reshape(weight.shape)
+        db = _colsum(dy)[0] if bias is not None and need_dw[1] else None
+        return da, [dw, db]
+    if kind == "qkv":
+        da, dw = _grad_contractions(
+            dy, a16,
+            lambda d: PACK.get_multi(params, f"qkv_t_{d}",
+                                     lambda ws: torch.cat([w.t().to(d) for w in ws], 1).contiguous()),
+            need_da, any(need_dw))
+        if dw is None:
+            return da, [None, None, None]
+        n = params[0].shape[0]
+        return da, [dw[:n], dw[n:2 * n], dw[2 * n:]]
+    if kind == "c3":
+        weight, bias = params
+        Cin, Cout, cin_p, cout_p = _c3_dims(weight, geo)
+        frames, Hi, Wi, Ho, Wo = geo["frames"], geo["Hi"], geo["Wi"], geo["Ho"], geo["Wo"]
+        Mout, Min = frames * Ho * Wo, frames * Hi * Wi
+        dyp = dy
+        if cout_p != Cout:
+            dyp = torch.zeros(Mout, cout_p, dtype=_f32, device=dev)
+            dyp[:, :Cout] = dy
+        dy16 = _cast16(dyp, dt)
+        da = dw = None
+        if need_da and geo["stride"] == 1:
+            # dgrad as an implicit-GEMM convolution of dY on the forward kernel (no dcol tensor, no col2im),
+            # at the output resolution; a fused x2 upsample then sums every 2 x 2 block back onto its source
+            wd = PACK.get(weight, f"c3d_{cin_p}_{cout_p}_{dt}", _pack_c3_dgrad(dt, cin_p, cout_p))
+            dxo = torch.empty(Mout, cin_p, dtype=_f32, device=dev)
+            _gemm(dy16, wd, dxo, M=Mout, mode=GEMM_CONV3X3,
+                  conv=dict(Cin=cout_p, Hi=Ho, Wi=Wo, Ho=Ho, Wo=Wo, stride=1, upsample=0))
+            if geo["upsample"]:
+                dxo = dxo.reshape(frames, Hi, 2, Wi, 2, cin_p).sum(dim=(2, 4)).reshape(Min, cin_p)
+            da = dxo[:, :Cin] if cin_p != Cin else dxo
+        col = None
+        if need_dw[0] or (need_da and da is None):
+            xg = _as_dtype(a16, dt)
+            col = torch.empty(Mout, 9 * cin_p, dtype=dt, device=dev)
+            check(lib.gcd_im2col3x3_f16(xg.data_ptr(), _ld(xg), col.data_ptr(), frames, cin_p, Hi, Wi, Ho, Wo,
+                                        geo["stride"], geo["upsample"], 0, _stream()), "gcd_im2col3x3_f16")
+        if need_da and da is None:
+            # stride 2 (the three Downsample convs): dcol = dY W by a plain GEMM, then the col2im gather
+            wt = PACK.get(weight, f"c3t_{cin_p}_{cout_p}_{dt}",
+                          lambda w: _pack_c3(dt, cin_p, cout_p)(w).t().contiguous())      # [9*cin_p, cout_p]
+            dcol = torch.empty(Mout, 9 * cin_p, dtype=_f32, device=dev)
+            _gemm(dy16, wt, dcol, M=Mout)
+            dxp = torch.empty(Min, cin_p, dtype=_f32, device=dev)
+            check(lib.gcd_col2im3x3_f32(dcol.data_ptr(), dxp.data_ptr(), cin_p, frames, cin_p, Hi, Wi, Ho, Wo,
+                                        geo["stride"], geo["upsample"], 0, _stream()), "gcd_col2im3x3_f32")
+            da = dxp[:, :Cin] if cin_p != Cin else dxp
+        if need_dw[0]:
+            dwp = torch.empty(cout_p, 9 * cin_p, dtype=_f32, device=dev)
+            _gemm(_t16_padded(dy16), _t16_padded(col), dwp, M=cout_p)       # dW = dY^T col, split-K over the tokens
+            dw = dwp.reshape(cout_p, 3, 3, cin_p).permute(0, 3, 1, 2)[:Cout, :Cin].contiguous()
+        db = _colsum(dy)[0] if bias is not None and need_dw[1] else None
+        return da, [dw, db]
+    if kind == "t3":
+        weight, bias = params
+        M, Cc = a16.shape
+        Cout = weight.shape[0]
+        dy16 = _cast16(dy, dt)
+        da = dw = None
+        if need_da:
+            wd = PACK.get(weight, f"t3d_{dt}", _pack_t3_dgrad(dt))          # [Cin, 3*Cout]
+            da = torch.empty(M, Cc, dtype=_f32, device=dev)
+            _gemm(dy16, wd, da, M=M, mode=GEMM_TEMPORAL3, conv=dict(Cin=Cout, T=geo["T"], HW=geo["HW"]))
+        if need_dw[0]:
+            xg = _as_dtype(a16, dt)
+            col = torch.empty(M, 3 * Cc, dtype=dt, device=dev)
+            check(lib.gcd_im2col_t3_f16(xg.data_ptr(), _ld(xg), col.data_ptr(), M, Cc, geo["T"], geo["HW"],
+                                        _stream()), "gcd_im2col_t3_f16")
+            dwp = torch.empty(Cout, 3 * Cc, dtype=_f32, device=dev)
+            _gemm(_t16_padded(dy16), _t16_padded(col), dwp, M=Cout)
+            dw = dwp.reshape(Cout, 3, Cc).permute(0, 2, 1).reshape(Cout, Cc, 3, 1, 1).contiguous()
+        db = _colsum(dy)[0] if bias is not None and need_dw[1] else None
+        return da, [dw, db]
+    raise ValueError(kind)
+
+
+# ---- norms on raw tensors (the standalone Functions further down and `Fused` share them) ----
+def _gn_fwd(x, gamma, beta, rows_per_inst, eps, silu):
+    M, Cc = x.shape
+    ninst = M // rows_per_inst
+    nch = ops.gn_nchunks(rows_per_inst, ninst)
+    partial = torch.empty(ninst * nch * 64, dtype=torch.float64, device=x.device)
+    stats = torch.empty(ninst * 64, dtype=_f32, device=x.device)
+    ops.groupnorm_stats(x, None, rows_per_inst, eps, partial, stats, nch)
+    y16 = torch.empty(M, Cc, dtype=_f16, device=x.device)
+    g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+    ops.groupnorm_apply(x, None, rows_per_inst, stats, g32, b32, silu, y16)
+    return y16, stats, g32, b32
+
+
+def _gn_bwd(x, dy, stats, g32, b32, rows_per_inst, silu):
+    M, Cc = x.shape
+    ninst = M // rows_per_inst
+    AB = torch.zeros(ninst, Cc, 2, dtype=torch.float64, device=x.device)
+    dx = torch.empty_like(x)
+    check(_lib.load().gcd_groupnorm_bwd(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), Cc, M, rows_per_inst,
+                                        stats.data_ptr(), g32.data_ptr(), b32.data_ptr(), int(silu),
+                                        AB.data_ptr(), dx.data_ptr(), _ld(dx), _stream()),
+          "gcd_groupnorm_bwd")
+    ab = AB.sum(0).float()
+    return dx, ab[:, 1].contiguous(), ab[:, 0].contiguous()
+
+
+def _ln_fwd(x, gamma, beta, eps):
+    y16 = torch.empty(x.shape, dtype=_f16, device=x.device)
+    g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+    ops.layernorm(x, g32, b32, y16, eps=eps)
+    return y16, g32
+
+
+def _ln_bwd(x, dy, g32, eps):
+    M, Cc = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.zeros(Cc, dtype=_f32, device=x.device)
+    db = torch.zeros(Cc, dtype=_f32, device=x.device)
+    check(_lib.load().gcd_layernorm_bwd(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), M, Cc, g32.data_ptr(),
+                                        eps, dx.data_ptr(), _ld(dx), dg.data_ptr(), db.data_ptr(),
+                                        _stream()), "gcd_layernorm_bwd")
+    return dx, dg, db
+
+
+class Fused(torch.autograd.Function):
+    """[norm ->] contraction [+ per-frame vector] [+ residual] as ONE graph node.
+
+    apply(spec, x, residual, rowvec, gamma, beta, *params)
+      spec: dict(kind = lin | qkv | c3 | t3, geo = {...}, norm = None | ("ln", eps) | ("gn", rows_per_inst,
+            eps, silu), rows_per_vec)
+    The normalised activation goes from the norm kernel to the GEMM as the 16-bit operand it is (no fp32
+    round trip, no cast pass); bias, the per-frame vector (emb_layers output, openaimodel.py:343-347) and the
+    residual ride in the GEMM epilogue as in the inference engine.  Backward: the contraction's dgrad / wgrad,
+    the norm's backward, d residual = dy, d rowvec = per-frame row sums of dy."""
+
+    @staticmethod
+    def forward(ctx, spec, x, residual, rowvec, gamma, beta, *params):
+        ops._need_gpu(x)
+        kind, geo, norm = spec["kind"], spec.get("geo"), spec.get("norm")
         dt = _dt(FWD_DTYPE)
-        x16 = _cast16(x, dt)
-        w16 = PACK.get(weight, f"t3_{FWD_DTYPE}", _pack_t3(dt))
-        y = torch.empty(M, Cout, dtype=_f32, device=x.device)
-        _gemm(x16, w16, y, M=M, mode=GEMM_TEMPORAL3, bias=None if bias is None else bias.detach().float(),
-              conv=dict(Cin=Cc, T=T, HW=HW))
-        ctx.save_for_backward(x16, weight)
-        ctx.T, ctx.HW, ctx.has_bias = T, HW, bias is not None
+        stats = g32 = b32 = None
+        if norm is not None:
+            x = x.contiguous()
+            if norm[0] == "ln":
+                y16, g32 = _ln_fwd(x, gamma, beta, norm[1])
+            else:
+                y16, stats, g32, b32 = _gn_fwd(x, gamma, beta, norm[1], norm[2], norm[3])
+            a16 = _as_dtype(y16, dt)
+        elif kind == "c3" and _c3_dims(params[0], geo)[2] != x.shape[1]:
+            a16 = torch.zeros(x.shape[0], _c3_dims(params[0], geo)[2], dtype=dt, device=x.device)
+            _cast16_into(x, a16[:, :x.shape[1]])
+        else:
+            a16 = _cast16(x, dt)
+        bias = None if kind == "qkv" else params[1]
+        y = _contract_fwd(kind, a16, params, geo,
+                          _epi(bias, None if rowvec is None else (rowvec, spec["rows_per_vec"]), residual))
+        ctx.spec = spec
+        ctx.n_params = len(params)
+        ctx.has = (residual is not None, rowvec is not None, bias is not None)
+        tensors = [a16] + [p for p in params if p is not None]
+        if norm is not None:
+            tensors += [x, g32] + ([stats, b32] if norm[0] == "gn" else [])
+        ctx.save_for_backward(*tensors)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x16, weight = ctx.saved_tensors
-        M, Cc = x16.shape
-        Cout = weight.shape[0]
-        dev = dy.device
+        spec = ctx.spec
+        kind, geo, norm = spec["kind"], spec.get("geo"), spec.get("norm")
+        has_res, has_vec, has_bias = ctx.has
+        saved = list(ctx.saved_tensors)
+        a16 = saved.pop(0)
+        if kind == "qkv":
+            params = tuple(saved[:3])
+            saved = saved[3:]
+        else:
+            weight = saved.pop(0)
+            bias = saved.pop(0) if has_bias else None
+            params = (weight, bias)
         dy = dy.contiguous()
-        dt = _dt(GRAD_DTYPE)
-        dy16 = _cast16(dy, dt)
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            wd = PACK.get(weight, f"t3d_{GRAD_DTYPE}", _pack_t3_dgrad(dt))          # [Cin, 3*Cout]
-            dx = torch.empty(M, Cc, dtype=_f32, device=dev)
-            _gemm(dy16, wd, dx, M=M, mode=GEMM_TEMPORAL3, conv=dict(Cin=Cout, T=ctx.T, HW=ctx.HW))
-        if ctx.needs_input_grad[1]:
-            xg = _as_dtype(x16, dt)
-            col = torch.empty(M, 3 * Cc, dtype=dt, device=dev)
-            check(_lib.load().gcd_im2col_t3_f16(xg.data_ptr(), _ld(xg), col.data_ptr(), M, Cc, ctx.T, ctx.HW,
-                                                _stream()), "gcd_im2col_t3_f16")
-            dwp = torch.empty(Cout, 3 * Cc, dtype=_f32, device=dev)
-            _gemm(_t16_padded(dy16), _t16_padded(col), dwp, M=Cout)
-            dw = dwp.reshape(Cout, 3, Cc).permute(0, 2, 1).reshape(Cout, Cc, 3, 1, 1).contiguous()
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy)[0]
-        return dx, dw, db, None, None
+        nig = ctx.needs_input_grad          # (spec, x, residual, rowvec, gamma, beta, *params)
+        need_x = nig[1]
+        need_norm_params = norm is not None and (nig[4] or nig[5])
+        need_da = need_x or need_norm_params
+        need_dw = list(nig[6:6 + ctx.n_params])
+        da, dps = _contract_bwd(kind, dy, a16, params, geo, need_da, need_dw)
+        dgamma = dbeta = None
+        if norm is None:
+            dx = da
+        elif da is None:
+            dx = None
+        elif norm[0] == "ln":
+            x, g32 = saved
+            dx, dgamma, dbeta = _ln_bwd(x, da.contiguous(), g32, norm[1])
+        else:
+            x, g32, stats, b32 = saved
+            dx, dgamma, dbeta = _gn_bwd(x, da.contiguous(), stats, g32, b32, norm[1], norm[3])
+        d_res = dy if has_res and nig[2] else None
+        d_vec = _colsum(dy, spec["rows_per_vec"]) if has_vec and nig[3] else None
+        return (None, dx if need_x else None, d_res, d_vec, dgamma, dbeta, *dps)
 
 
-def conv_t3(x, weight, bias, T, HW):
-    return ConvT3.apply(x, weight, bias, T, HW)
+def _fused(kind, x, params, geo=None, norm=None, residual=None, rowvec=None):
+    """norm: None | ("ln", module, eps) | ("gn", module, rows_per_inst, eps, silu); rowvec: (vector [n, N], rows)."""
+    spec = dict(kind=kind, geo=geo, norm=None, rows_per_vec=None if rowvec is None else rowvec[1])
+    gamma = beta = None
+    if norm is not None:
+        gamma, beta = norm[1].weight, norm[1].bias
+        spec["norm"] = (norm[0],) + tuple(norm[2:])
+    return Fused.apply(spec, x, residual, None if rowvec is None else rowvec[0], gamma, beta, *params)
+
+
+def linear(x, weight, bias=None, *, norm=None, residual=None, rowvec=None):
+    """y = [norm](x) @ W^T + b [+ rowvec per `rows` rows] [+ residual]; weight may be a 1x1 convolution's
+    [Cout, Cin, 1, 1]."""
+    return _fused("lin", x, (weight, bias), norm=norm, residual=residual, rowvec=rowvec)
+
+
+def qkv_linear(x, wq, wk, wv, *, norm=None):
+    return _fused("qkv", x, (wq, wk, wv), norm=norm)
+
+
+def conv3x3(x, weight, bias, frames, Hi, Wi, stride=1, upsample=False, *, norm=None, residual=None, rowvec=None):
+    if upsample:
+        Ho, Wo = 2 * Hi, 2 * Wi
+    else:
+        Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+    assert x.shape[0] == frames * Hi * Wi and x.shape[1] == weight.shape[1]
+    geo = dict(frames=frames, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo, stride=stride, upsample=int(upsample))
+    return _fused("c3", x, (weight, bias), geo=geo, norm=norm, residual=residual, rowvec=rowvec)
+
+
+def conv_t3(x, weight, bias, T, HW, *, norm=None, residual=None, rowvec=None):
+    return _fused("t3", x, (weight, bias), geo=dict(T=T, HW=HW), norm=norm, residual=residual, rowvec=rowvec)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -493,15 +598,7 @@ class GroupNormSiLU(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, rows_per_inst, eps, silu):
         ops._need_gpu(x)
         x = x.contiguous()
-        M, Cc = x.shape
-        ninst = M // rows_per_inst
-        nch = ops.gn_nchunks(rows_per_inst, ninst)
-        partial = torch.empty(ninst * nch * 64, dtype=torch.float64, device=x.device)
-        stats = torch.empty(ninst * 64, dtype=_f32, device=x.device)
-        ops.groupnorm_stats(x, None, rows_per_inst, eps, partial, stats, nch)
-        y16 = torch.empty(M, Cc, dtype=_f16, device=x.device)
-        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        ops.groupnorm_apply(x, None, rows_per_inst, stats, g32, b32, silu, y16)
+        y16, stats, g32, b32 = _gn_fwd(x, gamma, beta, rows_per_inst, eps, silu)
         ctx.save_for_backward(x, stats, g32, b32)
         ctx.rows, ctx.silu = rows_per_inst, bool(silu)
         return y16.float()
@@ -509,17 +606,8 @@ class GroupNormSiLU(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, stats, g32, b32 = ctx.saved_tensors
-        M, Cc = x.shape
-        ninst = M // ctx.rows
-        dy = dy.contiguous()
-        AB = torch.zeros(ninst, Cc, 2, dtype=torch.float64, device=x.device)
-        dx = torch.empty_like(x)
-        check(_lib.load().gcd_groupnorm_bwd(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), Cc, M, ctx.rows,
-                                            stats.data_ptr(), g32.data_ptr(), b32.data_ptr(), int(ctx.silu),
-                                            AB.data_ptr(), dx.data_ptr(), _ld(dx), _stream()),
-              "gcd_groupnorm_bwd")
-        ab = AB.sum(0).float()
-        return dx, ab[:, 1].contiguous(), ab[:, 0].contiguous(), None, None, None
+        dx, dg, db = _gn_bwd(x, dy.contiguous(), stats, g32, b32, ctx.rows, ctx.silu)
+        return dx, dg, db, None, None, None
 
 
 def group_norm(x, gamma, beta, rows_per_inst, eps=1e-5, silu=False):
@@ -531,9 +619,7 @@ class LayerNorm16(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, eps):
         ops._need_gpu(x)
         x = x.contiguous()
-        y16 = torch.empty(x.shape, dtype=_f16, device=x.device)
-        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        ops.layernorm(x, g32, b32, y16, eps=eps)
+        y16, g32 = _ln_fwd(x, gamma, beta, eps)
         ctx.save_for_backward(x, g32)
         ctx.eps = eps
         return y16.float()
@@ -541,14 +627,7 @@ class LayerNorm16(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, g32 = ctx.saved_tensors
-        M, Cc = x.shape
-        dy = dy.contiguous()
-        dx = torch.empty_like(x)
-        dg = torch.zeros(Cc, dtype=_f32, device=x.device)
-        db = torch.zeros(Cc, dtype=_f32, device=x.device)
-        check(_lib.load().gcd_layernorm_bwd(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), M, Cc, g32.data_ptr(),
-                                            ctx.eps, dx.data_ptr(), _ld(dx), dg.data_ptr(), db.data_ptr(),
-                                            _stream()), "gcd_layernorm_bwd")
+        dx, dg, db = _ln_bwd(x, dy.contiguous(), g32, ctx.eps)
         return dx, dg, db, None
 
 

@@ -164,19 +164,22 @@ __global__ __launch_bounds__(256) void col2im_t3_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rowblock_sum_kernel(const float* __restrict__ x, int64_t ldx,
                                                            int64_t rows, int N, float* __restrict__ out) {
-  __shared__ double red[4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  __shared__ double red[4][256];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = (blockIdx.x * 64 + cl) * 4;          // four columns per lane: 1 KB per wave and row
   const int64_t base = (int64_t)blockIdx.y * rows;
-  double s = 0.0;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
   if (col < N)
-    for (int64_t r = (int64_t)blockIdx.z * 4 + rl; r < rows; r += (int64_t)gridDim.z * 4)
-      s += (double)x[(base + r) * ldx + col];
-  red[rl][threadIdx.x & 63] = s;
+    for (int64_t r = (int64_t)blockIdx.z * 4 + rl; r < rows; r += (int64_t)gridDim.z * 4) {
+      const f32x4 v = *(const f32x4*)(x + (base + r) * ldx + col);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += (double)v[e];
+    }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[rl][4 * cl + e] = s[e];
   __syncthreads();
-  if (rl == 0 && col < N) {
-    const int c = threadIdx.x;
-    atomicAdd(out + (int64_t)blockIdx.y * N + col, (float)(red[0][c] + red[1][c] + red[2][c] + red[3][c]));
-  }
+  const int c = threadIdx.x, oc = blockIdx.x * 256 + c;
+  if (oc < N) atomicAdd(out + (int64_t)blockIdx.y * N + oc, (float)(red[0][c] + red[1][c] + red[2][c] + red[3][c]));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -351,16 +354,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
       }
     }
   }
+  // the four waves of a workgroup combine their column sums in LDS: one fp32 atomic per column and WORKGROUP
+  // (at one per wave, 8192 waves x 2 C atomics on 2 C addresses made this kernel 10x slower than its traffic)
+  __shared__ float red[4][2 * 1280];
+  const int w = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < KM; ++k) {
     const int c = 256 * k + 4 * lane;
     if (c < C) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        atomicAdd(dgamma + c + e, ag[k][e]);
-        atomicAdd(dbeta + c + e, ab[k][e]);
-      }
+      *(f32x4*)(&red[w][c]) = ag[k];
+      *(f32x4*)(&red[w][1280 + c]) = ab[k];
     }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dgamma + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    atomicAdd(dbeta + c, red[0][1280 + c] + red[1][1280 + c] + red[2][1280 + c] + red[3][1280 + c]);
   }
 }
 
@@ -633,12 +642,14 @@ extern "C" int gcd_rowblock_sum_f32(const float* x, int64_t ldx, int64_t M, int 
                                     float* out_zeroed, void* stream) {
   GCD_CHECK_ARG(x && out_zeroed && M > 0 && N > 0 && rows_per_block > 0 && M % rows_per_block == 0,
                 "gcd_rowblock_sum_f32: M=%lld rows_per_block=%lld", (long long)M, (long long)rows_per_block);
+  GCD_CHECK_ARG(N % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0,
+                "gcd_rowblock_sum_f32: N=%d / ldx=%lld must be multiples of 4, x 16-byte aligned", N, (long long)ldx);
   const int64_t nblk = M / rows_per_block;
   GCD_CHECK_ARG(nblk <= 65535, "gcd_rowblock_sum_f32: too many blocks");
   int64_t nsplit = rows_per_block / 256;
   if (nsplit < 1) nsplit = 1;
   if (nsplit > 64) nsplit = 64;
-  hipLaunchKernelGGL(rowblock_sum_kernel, dim3((N + 63) / 64, (unsigned)nblk, (unsigned)nsplit), dim3(256), 0,
+  hipLaunchKernelGGL(rowblock_sum_kernel, dim3((N + 255) / 256, (unsigned)nblk, (unsigned)nsplit), dim3(256), 0,
                      (hipStream_t)stream, x, ldx, rows_per_block, N, out_zeroed);
   GCD_CHECK_LAUNCH();
   return 0;
@@ -682,7 +693,7 @@ extern "C" int gcd_layernorm_bwd(const float* x, int64_t ldx, const float* dy, i
   GCD_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 1280 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && M > 0,
                 "gcd_layernorm_bwd: C=%d (multiple of 4, <= 1280)", C);
   int64_t blocks = (M + 3) / 4;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 768) blocks = 768;      // 3 workgroups per CU; every workgroup ends with 2 C atomics
   hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy,
                      M, C, gamma, eps, dx, lddx, dgamma_zeroed, dbeta_zeroed);
   GCD_CHECK_LAUNCH();

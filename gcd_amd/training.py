@@ -83,33 +83,29 @@ def _alpha(blender, ioi: torch.Tensor, frames: int) -> torch.Tensor:
 # blocks
 # ------------------------------------------------------------------------------------------------
 def _resblock_2d(rb, x, emb, frames, H, W):
-    """ResBlock._forward, dims 2 (openaimodel.py:331-357)."""
+    """ResBlock._forward, dims 2 (openaimodel.py:331-357): every GroupNorm+SiLU feeds its convolution as the
+    16-bit operand it produces, the emb_layers vector and the skip ride in the convolutions' epilogues."""
     HW = H * W
-    h = A.group_norm(x, rb.in_layers[0].weight, rb.in_layers[0].bias, HW, 1e-5, True)
-    h = A.conv3x3(h, rb.in_layers[2].weight, rb.in_layers[2].bias, frames, H, W)
     e = A.linear(_silu(emb), rb.emb_layers[1].weight, rb.emb_layers[1].bias)
-    h = h + _per_frame(e, HW)
-    h = A.group_norm(h, rb.out_layers[0].weight, rb.out_layers[0].bias, HW, 1e-5, True)
-    h = A.conv3x3(h, rb.out_layers[3].weight, rb.out_layers[3].bias, frames, H, W)
+    h = A.conv3x3(x, rb.in_layers[2].weight, rb.in_layers[2].bias, frames, H, W,
+                  norm=("gn", rb.in_layers[0], HW, 1e-5, True), rowvec=(e, HW))
     if isinstance(rb.skip_connection, nn.Identity):
         skip = x
     else:
-        w = rb.skip_connection.weight
-        skip = A.linear(x, w.reshape(w.shape[0], w.shape[1]), rb.skip_connection.bias)
-    return skip + h
+        skip = A.linear(x, rb.skip_connection.weight, rb.skip_connection.bias)
+    return A.conv3x3(h, rb.out_layers[3].weight, rb.out_layers[3].bias, frames, H, W,
+                     norm=("gn", rb.out_layers[0], HW, 1e-5, True), residual=skip)
 
 
 def _resblock_time(ts, x, emb, T, HW):
     """The time_stack ResBlock, dims 3, kernel (3,1,1), GroupNorm over T*H*W per clip, per-frame emb
     (`exchange_temb_dims`, openaimodel.py:353-354)."""
     rows = T * HW
-    h = A.group_norm(x, ts.in_layers[0].weight, ts.in_layers[0].bias, rows, 1e-5, True)
-    h = A.conv_t3(h, ts.in_layers[2].weight, ts.in_layers[2].bias, T, HW)
     e = A.linear(_silu(emb), ts.emb_layers[1].weight, ts.emb_layers[1].bias)
-    h = h + _per_frame(e, HW)
-    h = A.group_norm(h, ts.out_layers[0].weight, ts.out_layers[0].bias, rows, 1e-5, True)
-    h = A.conv_t3(h, ts.out_layers[3].weight, ts.out_layers[3].bias, T, HW)
-    return x + h
+    h = A.conv_t3(x, ts.in_layers[2].weight, ts.in_layers[2].bias, T, HW,
+                  norm=("gn", ts.in_layers[0], rows, 1e-5, True), rowvec=(e, HW))
+    return A.conv_t3(h, ts.out_layers[3].weight, ts.out_layers[3].bias, T, HW,
+                     norm=("gn", ts.out_layers[0], rows, 1e-5, True), residual=x)
 
 
 def _video_resblock(rb: VideoResBlock, x, emb, frames, T, H, W, ioi):
@@ -117,16 +113,18 @@ def _video_resblock(rb: VideoResBlock, x, emb, frames, T, H, W, ioi):
     xs = _resblock_2d(rb, x, emb, frames, H, W)
     xt = _resblock_time(rb.time_stack, xs, emb, T, H * W)
     a = _per_frame(_alpha(rb.time_mixer, ioi, frames), H * W)
-    return a * xs + (1.0 - a) * xt
+    return torch.lerp(xt, xs, a)            # alpha x_s + (1 - alpha) x_t   (util.py:358-369)
 
 
-def _self_attention(att, x, kind, dims):
-    qkv = A.qkv_linear(x, att.to_q.weight, att.to_k.weight, att.to_v.weight)
+def _self_attention(att, x, kind, dims, norm=None, residual=None, rowvec=None):
+    """attn1: q | k | v in one GEMM on the (LayerNorm'ed) input, the attention core, to_out (+ per-frame / per-clip
+    vector: the one-key cross-attention that follows; + residual)."""
+    qkv = A.qkv_linear(x, att.to_q.weight, att.to_k.weight, att.to_v.weight, norm=norm)
     if kind == "spatial":
         o = A.spatial_attention(qkv, *dims)
     else:
         o = A.temporal_attention(qkv, *dims)
-    return A.linear(o, att.to_out[0].weight, att.to_out[0].bias)
+    return A.linear(o, att.to_out[0].weight, att.to_out[0].bias, residual=residual, rowvec=rowvec)
 
 
 def _cross_attention_one_key(att, ctx_rows: torch.Tensor) -> torch.Tensor:
@@ -136,40 +134,40 @@ def _cross_attention_one_key(att, ctx_rows: torch.Tensor) -> torch.Tensor:
     return A.linear(A.linear(ctx_rows, att.to_v.weight, None), att.to_out[0].weight, att.to_out[0].bias)
 
 
-def _ff(ff, x):
-    h = A.linear(x, ff.net[0].proj.weight, ff.net[0].proj.bias)
-    return A.linear(A.geglu(h), ff.net[2].weight, ff.net[2].bias)
+def _ff(ff, x, norm=None, residual=None):
+    h = A.linear(x, ff.net[0].proj.weight, ff.net[0].proj.bias, norm=norm)
+    return A.linear(A.geglu(h), ff.net[2].weight, ff.net[2].bias, residual=residual)
 
 
-def _ln(m, x):
-    return A.layer_norm(x, m.weight, m.bias, 1e-5)
+def _ln(m):
+    return ("ln", m, 1e-5)
 
 
 def _transformer(tr: SpatialVideoTransformer, x, context2d, frames, T, H, W, ioi):
-    """SpatialVideoTransformer.forward (video_attention.py:230-301) on token-major rows."""
+    """SpatialVideoTransformer.forward (video_attention.py:230-301) on token-major rows.  Every LayerNorm is
+    the prologue of the GEMM it feeds, every `+ x` the epilogue of the GEMM that produces the other addend."""
     HW = H * W
     clips = frames // T
     heads = tr.heads
-    x_in = x
-    h = A.group_norm(x, tr.norm.weight, tr.norm.bias, HW, 1e-6, False)
-    h = A.linear(h, tr.proj_in.weight, tr.proj_in.bias)
+    h = A.linear(x, tr.proj_in.weight, tr.proj_in.bias, norm=("gn", tr.norm, HW, 1e-6, False))
     fidx = torch.arange(T, device=x.device, dtype=torch.float32).repeat(clips)
     pos = _mlp(tr.time_pos_embed, _timestep_embedding(fidx, tr.in_channels, tr.max_time_embed_period))
     for sb, tb in zip(tr.transformer_blocks, tr.time_stack):
         # spatial BasicTransformerBlock (attention.py:551-572)
-        h = _self_attention(sb.attn1, _ln(sb.norm1, h), "spatial", (frames, HW, heads)) + h
-        h = _per_frame(_cross_attention_one_key(sb.attn2, context2d), HW) + h
-        h = _ff(sb.ff, _ln(sb.norm3, h)) + h
+        ca = _cross_attention_one_key(sb.attn2, context2d)                  # [frames, C]
+        h = _self_attention(sb.attn1, h, "spatial", (frames, HW, heads), norm=_ln(sb.norm1), residual=h,
+                            rowvec=(ca, HW))
+        h = _ff(sb.ff, h, norm=_ln(sb.norm3), residual=h)
         # temporal VideoTransformerBlock (video_attention.py:109-140) on x + frame position embedding
         xm = h + _per_frame(pos, HW)
-        xm = _ff(tb.ff_in, _ln(tb.norm_in, xm)) + xm
-        xm = _self_attention(tb.attn1, _ln(tb.norm1, xm), "temporal", (clips, T, HW, heads)) + xm
-        xm = _per_frame(_cross_attention_one_key(tb.attn2, context2d[::T]), T * HW) + xm
-        xm = _ff(tb.ff, _ln(tb.norm3, xm)) + xm
+        xm = _ff(tb.ff_in, xm, norm=_ln(tb.norm_in), residual=xm)
+        ca = _cross_attention_one_key(tb.attn2, context2d[::T])             # [clips, C]: first frame's context
+        xm = _self_attention(tb.attn1, xm, "temporal", (clips, T, HW, heads), norm=_ln(tb.norm1), residual=xm,
+                             rowvec=(ca, T * HW))
+        xm = _ff(tb.ff, xm, norm=_ln(tb.norm3), residual=xm)
         a = _per_frame(_alpha(tr.time_mixer, ioi, frames), HW)
-        h = a * h + (1.0 - a) * xm
-    h = A.linear(h, tr.proj_out.weight, tr.proj_out.bias)
-    return h + x_in
+        h = torch.lerp(xm, h, a)
+    return A.linear(h, tr.proj_out.weight, tr.proj_out.bias, residual=x)
 
 
 def unet_forward_train(unet: VideoUNet, x: torch.Tensor, timesteps: torch.Tensor, context: torch.Tensor,
@@ -233,8 +231,7 @@ def unet_forward_train(unet: VideoUNet, x: torch.Tensor, timesteps: torch.Tensor
     h = run(unet.middle_block, h)
     for blk in unet.output_blocks:
         h = run(blk, torch.cat([h, hs.pop()], dim=1))
-    h = A.group_norm(h, unet.out[0].weight, unet.out[0].bias, H * W, 1e-5, True)
-    h = A.conv3x3(h, unet.out[2].weight, unet.out[2].bias, N, H, W)
+    h = A.conv3x3(h, unet.out[2].weight, unet.out[2].bias, N, H, W, norm=("gn", unet.out[0], H * W, 1e-5, True))
     return _from_tokens(h, N, H, W)
 
 

@@ -264,6 +264,79 @@ def test_qkv_linear_backward(gpu):
         _check("dw" + n, a.grad, b.grad)
 
 
+def test_fused_node_norm_contraction_vector_residual(gpu):
+    """autograd_ops.Fused: [LayerNorm | GroupNorm+SiLU] -> [Linear | Conv3x3 | Conv (3,1,1)] + per-frame vector +
+    residual as ONE graph node, against the same chain of torch ops: output and every gradient (input, norm
+    affine, weight, bias, vector, residual)."""
+    from gcd_amd import autograd_ops as A
+    g = _gen(43)
+    frames, H, W, C, Co = 4, 8, 8, 64, 128
+    HW, M = H * W, 4 * 64
+    # ---- LayerNorm -> Linear + per-frame vector + residual ----
+    x = torch.randn(M, C, generator=g)
+    ln = torch.nn.LayerNorm(C)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.2 * torch.randn(C, generator=g))
+        ln.bias.copy_(0.1 * torch.randn(C, generator=g))
+    w, b = torch.randn(Co, C, generator=g) / math.sqrt(C), torch.randn(Co, generator=g)
+    vec, res, dy = torch.randn(frames, Co, generator=g), torch.randn(M, Co, generator=g), torch.randn(M, Co, generator=g)
+    leaves = [_leaf(t) for t in (x, w, b, vec, res)]
+    xr, wr, br, vr, rr = leaves
+    yr = F.linear(ln(xr), wr, br) + vr.repeat_interleave(HW, 0) + rr
+    yr.backward(dy)
+    lg = torch.nn.LayerNorm(C).to(gpu)
+    lg.load_state_dict(ln.state_dict())
+    xg, wg, bg, vg, rg = (_leaf(t, gpu) for t in (x, w, b, vec, res))
+    y = A.linear(xg, wg, bg, norm=("ln", lg, 1e-5), residual=rg, rowvec=(vg, HW))
+    print("LayerNorm -> Linear + vector + residual:")
+    _check("y", y, yr, 1e-3)
+    y.backward(dy.to(gpu))
+    for n, a_, b_ in [("dx", xg, xr), ("dw", wg, wr), ("db", bg, br), ("dvec", vg, vr), ("dres", rg, rr),
+                      ("dgamma", lg.weight, ln.weight), ("dbeta", lg.bias, ln.bias)]:
+        _check(n, a_.grad, b_.grad)
+    # ---- GroupNorm + SiLU -> Conv3x3 + per-frame vector + residual ----
+    x = torch.randn(frames, C, H, W, generator=g)
+    gn = torch.nn.GroupNorm(32, C)
+    with torch.no_grad():
+        gn.weight.copy_(1 + 0.2 * torch.randn(C, generator=g))
+        gn.bias.copy_(0.1 * torch.randn(C, generator=g))
+    w, b = torch.randn(Co, C, 3, 3, generator=g) / math.sqrt(9 * C), torch.randn(Co, generator=g)
+    res = torch.randn(frames, Co, H, W, generator=g)
+    dy = torch.randn(frames, Co, H, W, generator=g)
+    xr, wr, br, vr, rr = (_leaf(t) for t in (x, w, b, vec, res))
+    yr = F.conv2d(F.silu(gn(xr)), wr, br, padding=1) + vr[:, :, None, None] + rr
+    yr.backward(dy)
+    gg = torch.nn.GroupNorm(32, C).to(gpu)
+    gg.load_state_dict(gn.state_dict())
+    xg, wg, bg, vg, rg = _leaf(_tok(x), gpu), _leaf(w, gpu), _leaf(b, gpu), _leaf(vec, gpu), _leaf(_tok(res), gpu)
+    y = A.conv3x3(xg, wg, bg, frames, H, W, norm=("gn", gg, HW, 1e-5, True), residual=rg, rowvec=(vg, HW))
+    print("GroupNorm+SiLU -> Conv3x3 + vector + residual:")
+    _check("y", y, _tok(yr), 1e-3)
+    y.backward(_tok(dy).to(gpu))
+    for n, a_, b_ in [("dx", xg.grad, _tok(xr.grad)), ("dw", wg.grad, wr.grad), ("db", bg.grad, br.grad),
+                      ("dvec", vg.grad, vr.grad), ("dres", rg.grad, _tok(rr.grad)),
+                      ("dgamma", gg.weight.grad, gn.weight.grad), ("dbeta", gg.bias.grad, gn.bias.grad)]:
+        _check(n, a_, b_)
+    # ---- GroupNorm over T*H*W + SiLU -> Conv (3,1,1) + residual ----
+    clips, T = 2, 2
+    gn3 = torch.nn.GroupNorm(32, C)
+    w3 = torch.randn(C, C, 3, 1, 1, generator=g) / math.sqrt(3 * C)
+    x5 = x.reshape(clips, T, C, H, W).permute(0, 2, 1, 3, 4).contiguous()            # b c t h w
+    xr, wr = _leaf(x5), _leaf(w3)
+    yr = F.conv3d(F.silu(gn3(xr)), wr, None, padding=(1, 0, 0)) + xr
+    dy5 = torch.randn(yr.shape, generator=g)
+    yr.backward(dy5)
+    tok5 = lambda t: t.permute(0, 2, 3, 4, 1).reshape(clips * T * HW, C).contiguous()    # noqa: E731
+    g3 = torch.nn.GroupNorm(32, C).to(gpu)
+    xg, wg = _leaf(tok5(x5), gpu), _leaf(w3, gpu)
+    y = A.conv_t3(xg, wg, None, T, HW, norm=("gn", g3, T * HW, 1e-5, True), residual=xg)
+    print("GroupNorm(T*H*W)+SiLU -> Conv (3,1,1) + residual (the block input itself):")
+    _check("y", y, tok5(yr), 1e-3)
+    y.backward(tok5(dy5).to(gpu))
+    _check("dx", xg.grad, tok5(xr.grad))
+    _check("dw", wg.grad, wr.grad)
+
+
 # -------------------------------------------------------------------------------------- blocks, network
 def _tiny_unet(gpu, salt=0):
     from gcd_amd.video_model import VideoUNet

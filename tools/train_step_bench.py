@@ -2,9 +2,8 @@
 cfg4's per-GPU shape (batch 2 clips x 14 frames, 32x48 latents = 256x384 pixels, N = 28 frames, no CFG;
 configs/train_kubric_max90.yaml:209-210,234) on the HIP training path: StandardDiffusionLoss forward,
 backward through gcd_amd.autograd_ops, AdamHIP step.  Reports wall time per phase and the algorithmic
-TFLOP/s (12.53 TFLOP forward at this shape; backward = 2x forward).  This path is a
-correctness-first vertical slice (unfused, im2col convolutions, per-(frame, head) attention backward):
-the number documents where it stands, it is not the repo's headline metric.
+TFLOP/s (12.53 TFLOP forward at this shape; backward = 2x forward; the re-forward of the
+activation checkpointing is executed but not counted).  Not the repo's headline metric.
 
     python tools/train_step_bench.py [--steps 3] [--latent 32x48]
 """
@@ -25,8 +24,12 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--latent", default="32x48")
     ap.add_argument("--clips", type=int, default=2)
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"],
+                    help="operand type of the GEMM-family contractions, forward and backward (cfg4 names bf16)")
     a = ap.parse_args()
+    from gcd_amd import autograd_ops as AO
     from gcd_amd import training as TR
+    AO.set_train_dtype(a.dtype)
     dev = torch.device("cuda:0")
     T = 14
     h, w = (int(v) for v in a.latent.split("x"))
@@ -65,7 +68,7 @@ def main():
     f, b, o = (sorted(t[i] for t in times)[len(times) // 2] for i in range(3))
     tf_fwd = 12.531 * (h * w) / (32 * 48) * a.clips / 2
     print(json.dumps({
-        "what": "one fine-tune step, full-width Kubric VideoUNet, HIP training path (vertical slice)",
+        "what": "one fine-tune step, full-width Kubric VideoUNet, HIP training path", "gemm_operands": a.dtype,
         "frames": BT, "latent": [h, w], "forward_s": round(f, 3), "backward_s": round(b, 3), "adam_s": round(o, 3),
         "step_s": round(f + b + o, 3), "algorithmic_tflop": round(3 * tf_fwd, 2),
         "tflops": round(3 * tf_fwd / (f + b + o), 1), "loss_finite": finite,
