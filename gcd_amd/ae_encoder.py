@@ -143,9 +143,30 @@ def encode_mode(encoder: Encoder, x: torch.Tensor, quant_conv: Optional[nn.Conv2
     mean half of the channels."""
     moments = encoder(x)
     if quant_conv is not None:
-        moments = torch.nn.functional.conv2d(moments, quant_conv.weight.to(moments.dtype),
-                                             quant_conv.bias.to(moments.dtype))
+        moments = _conv1x1_hip(moments, quant_conv)
     return torch.chunk(moments, 2, dim=1)[0]
+
+
+def _conv1x1_hip(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
+    """A 1x1 convolution of an NCHW fp32 tensor on gcd_gemm_f16 (the 8 -> 8 channel `quant_conv`): channels
+    zero-padded to the GEMM's 64-deep K granule / 16-row N granule, fp16 operands, fp32 accumulation and bias —
+    the same arithmetic as every other contraction of the encoder.  torch only re-lays the tensor out."""
+    from . import ops
+    n, c, h, w = x.shape
+    co = conv.out_channels
+    assert tuple(conv.kernel_size) == (1, 1) and conv.in_channels == c
+    kp, np_ = (c + 63) // 64 * 64, (co + 15) // 16 * 16
+    M = n * h * w
+    tok = torch.zeros(M, kp, dtype=torch.float16, device=x.device)
+    tok[:, :c] = x.permute(0, 2, 3, 1).reshape(M, c)
+    wq = torch.zeros(np_, kp, dtype=torch.float16, device=x.device)
+    wq[:co, :c] = conv.weight.detach().reshape(co, c)
+    b = torch.zeros(np_, dtype=torch.float32, device=x.device)
+    if conv.bias is not None:
+        b[:co] = conv.bias.detach().float()
+    out = torch.empty(M, np_, dtype=torch.float32, device=x.device)
+    ops.gemm(tok, wq, out, M=M, bias=b)
+    return out[:, :co].reshape(n, h, w, co).permute(0, 3, 1, 2).contiguous()
 
 
 class EncoderEngine(DecoderEngine):

@@ -383,11 +383,51 @@ __global__ __launch_bounds__(256) void transpose_f16_kernel(const f16* __restric
   }
 }
 
+// The same transpose on 16-byte vectors (the operands of the fine-tune step's weight gradients are whole
+// activation tensors transposed so that the token axis becomes the GEMM's contraction axis): a 64 x 64 tile is
+// loaded as f16x8 rows, read back column-wise from LDS and stored as two f16x8 per lane — 32 contiguous bytes of
+// an output row per lane instead of 2.  Rows r >= R of the tile enter as zeros and are written too (up to Rp
+// output columns): the zero padding of the contraction axis costs no separate fill.
+__global__ __launch_bounds__(256) void transpose_f16_vec_kernel(const f16* __restrict__ x, int64_t ldx,
+                                                                f16* __restrict__ y, int64_t ldy, int R,
+                                                                int C, int Rp) {
+  __shared__ __attribute__((aligned(16))) f16 tile[64][72];
+  const int t = threadIdx.x;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = i * 256 + t;
+    const int r = p >> 3, ch = p & 7;
+    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (r0 + r < R && c0 + ch * 8 < C) v = *(const f16x8*)(x + (int64_t)(r0 + r) * ldx + c0 + ch * 8);
+    *(f16x8*)(&tile[r][ch * 8]) = v;
+  }
+  __syncthreads();
+  const int c = t >> 2, rg = (t & 3) * 16;
+  if (c0 + c < C && r0 + rg < Rp) {
+    f16x8 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      o0[e] = tile[rg + e][c];
+      o1[e] = tile[rg + 8 + e][c];
+    }
+    f16* dst = y + (int64_t)(c0 + c) * ldy + r0 + rg;
+    *(f16x8*)dst = o0;
+    *(f16x8*)(dst + 8) = o1;
+  }
+}
+
 extern "C" int gcd_transpose_f16(const void* x, int64_t ldx, void* y, int64_t ldy, int R, int C,
                                  void* stream) {
   GCD_CHECK_ARG(x && y, "gcd_transpose_f16: null pointer");
   GCD_CHECK_ARG(R > 0 && C > 0 && ldx >= C && ldy >= R, "gcd_transpose_f16: R=%d C=%d ldx=%lld ldy=%lld",
                 R, C, (long long)ldx, (long long)ldy);
+  if (R % 16 == 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+    hipLaunchKernelGGL(transpose_f16_vec_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0,
+                       (hipStream_t)stream, (const f16*)x, ldx, (f16*)y, ldy, R, C, R);
+    GCD_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(transpose_f16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0,
                      (hipStream_t)stream, (const f16*)x, ldx, (f16*)y, ldy, R, C);
   GCD_CHECK_LAUNCH();

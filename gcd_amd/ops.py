@@ -68,11 +68,23 @@ def tune_set(knob: int, value: int) -> None:
 
 
 def _need_gpu(*ts) -> None:
+    """Every kernel launches on the CURRENT device's current stream (`_stream`): operands must be GPU tensors of
+    that device.  A tensor of another GPU is an error here, not a silent launch on the wrong device — wrap the call
+    in `torch.cuda.device(t.device)` (engine.run does that itself)."""
+    cur = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise _lib.GcdError(
                 "gcd_amd kernels run on an AMD GPU only (got a CPU tensor); there is no CPU fallback"
             )
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise _lib.GcdError(
+                f"operand on cuda:{t.device.index} but the current device is cuda:{cur}: gcd_amd launches on the "
+                "current device's current stream; make the operand's device current (torch.cuda.device(...))")
 
 
 def _p(t: Optional[torch.Tensor]):

@@ -46,6 +46,75 @@ class FusedDenoiser:
         return self.denoiser(self.network, input, sigma, c, **self.additional_model_inputs)
 
 
+def _closure_signature(fn, role):
+    """The body of a closure as a list of (opcode, operand) with every captured variable replaced by the ROLE of
+    the object it holds (`role(cell_contents)`), locals by their index and attributes / constants by value: two
+    closures with the same signature execute the same instructions on objects of the same roles, whatever their
+    variables are called."""
+    import dis
+    code = fn.__code__
+    sig = []
+    for ins in dis.get_instructions(code):
+        if ins.opname in ("LOAD_DEREF", "LOAD_CLOSURE", "LOAD_CLASSDEREF"):
+            if ins.argval not in code.co_freevars:
+                return None
+            try:
+                v = fn.__closure__[code.co_freevars.index(ins.argval)].cell_contents
+            except ValueError:               # empty cell
+                return None
+            sig.append((ins.opname, role(v)))
+        elif ins.opname == "LOAD_FAST":
+            sig.append((ins.opname, ins.arg))
+        elif ins.opname in ("LOAD_ATTR", "LOAD_METHOD", "LOAD_CONST", "LOAD_GLOBAL", "LOAD_NAME", "KW_NAMES"):
+            sig.append((ins.opname, repr(ins.argval)))
+        elif ins.opname in ("RESUME", "COPY_FREE_VARS", "NOP", "CACHE", "PRECALL"):
+            continue
+        else:
+            sig.append((ins.opname, ins.arg))
+    return tuple(sig)
+
+
+def _closure_templates():
+    """Signatures of the closure bodies `fused_from_closure` accepts, compiled by THIS interpreter: the reference's
+    (diffusion.py:531-532 with keyword inputs, :446-447 without) and the same calls on directly captured objects."""
+    class _Role:
+        pass
+    E, DEN, NET, D = _Role(), _Role(), _Role(), {}
+    names = {id(E): "engine", id(DEN): "denoiser", id(NET): "network"}
+
+    def role(v):
+        return "kwargs" if isinstance(v, dict) else names.get(id(v))
+
+    def engine_kw(input, sigma, c):
+        return E.denoiser(E.model, input, sigma, c, **D)
+
+    def engine_plain(input, sigma, c):
+        return E.denoiser(E.model, input, sigma, c)
+
+    def direct_kw(input, sigma, c):
+        return DEN(NET, input, sigma, c, **D)
+
+    def direct_plain(input, sigma, c):
+        return DEN(NET, input, sigma, c)
+
+    return {_closure_signature(f, role) for f in (engine_kw, engine_plain, direct_kw, direct_plain)}
+
+
+_CLOSURE_TEMPLATES = _closure_templates()
+
+
+def _closure_role(v):
+    if isinstance(v, dict):
+        return "kwargs"
+    if isinstance(v, Denoiser):
+        return "denoiser"
+    if isinstance(v, OpenAIWrapper):
+        return "network"
+    if isinstance(getattr(v, "denoiser", None), Denoiser) and isinstance(getattr(v, "model", None), OpenAIWrapper):
+        return "engine"
+    return None
+
+
 def fused_from_closure(fn) -> Optional[FusedDenoiser]:
     """Recover (denoiser, network, additional_model_inputs) from the closure that
     `DiffusionEngine.sample_video` / `sample` build around the plugin stack (diffusion.py:526-532,
@@ -58,8 +127,10 @@ def fused_from_closure(fn) -> Optional[FusedDenoiser]:
     with no edit of the reference.  Accepted shapes: a plain 3-argument Python function whose cells
     hold either an engine object exposing `.denoiser` (a gcd_amd Denoiser) and `.model` (a gcd_amd
     OpenAIWrapper), or those two objects directly, plus at most one dict of keyword inputs; the
-    body may reference no globals and no attribute names other than `denoiser` / `model` (a closure
-    that does anything else is left on the generic path).  Returns None when it does not match."""
+    body must be, bytecode for bytecode, that call (`_closure_templates`: the reference's form or the same call on
+    directly captured objects) — a closure that does anything else is left on the generic path.  Brittle by
+    design: any upstream edit of diffusion.py:526-532 falls back to the generic (slower, same results) path;
+    `EulerEDMSampler.last_path` records which path ran.  Returns None when it does not match."""
     import types
     if os.environ.get("GCD_FUSE_CLOSURE", "1") == "0":
         return None
@@ -69,6 +140,10 @@ def fused_from_closure(fn) -> Optional[FusedDenoiser]:
     if code.co_argcount != 3 or code.co_kwonlyargcount or (code.co_flags & 0x0C):   # *args / **kwargs
         return None
     if not set(code.co_names) <= {"denoiser", "model"}:
+        return None
+    # the BODY must be one of the two known forms, instruction for instruction: a closure with the same names
+    # that scales its input, reorders arguments or post-processes the output stays on the generic path
+    if _closure_signature(fn, _closure_role) not in _CLOSURE_TEMPLATES:
         return None
     den = net = extra = None
     for cell in fn.__closure__:

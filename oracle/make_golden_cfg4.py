@@ -69,6 +69,7 @@ def main():
     noised = x0 + noise * sig[:, None, None, None]
     t0 = time.time()
     out = den(model, noised, sig, cond, num_video_frames=T, image_only_indicator=torch.zeros(B, T))
+    out = out.contiguous()      # the CPU convolution returns channels_last strides; get_loss uses .view (loss.py:244)
     w = loss_fn.loss_weighting(sig)[:, None, None, None]
     loss = loss_fn.get_loss(out, x0, w, {"global_step": STEP}).mean()
     t1 = time.time()

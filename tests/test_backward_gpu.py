@@ -505,6 +505,88 @@ def test_unet_training_step_vs_oracle(gpu, step):
     assert moved > 0
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_training_step_full_width_cfg4_vs_reference_golden(gpu, dtype):
+    """BASELINE.json cfg4 at its own shape: ONE fine-tune step of the full-width 1.53 B-parameter Kubric VideoUNet on
+    2 clips x 14 frames of 32 x 48 latents (N = 28, activation checkpointing as in every GCD config) against the
+    UNMODIFIED reference classes' fp32 torch.autograd run on the CPU (oracle/make_golden_cfg4.py): loss, denoiser
+    output, and for each of the ~1400 parameter gradients its norm and 128 strided samples.  Run with fp16 GEMM
+    operands (the inference engine's arithmetic) and with bf16 (what cfg4 names); the tolerance met is printed."""
+    from pathlib import Path
+    gold = Path(__file__).resolve().parent / "golden" / "train_kubric_32x48.pt"
+    if not gold.exists():
+        pytest.skip("tests/golden/train_kubric_32x48.pt has not been generated (python -m oracle.make_golden_cfg4)")
+    from gcd_amd import autograd_ops as A
+    from gcd_amd import training as TR
+    from gcd_amd.video_model import VideoUNet
+    from oracle.make_golden_cfg4 import inputs
+    from oracle.make_golden_fullres import sample
+    G = torch.load(gold)
+    cfg = O.KUBRIC
+    with torch.device("meta"):
+        net = VideoUNet(**cfg.as_reference_kwargs())
+    sd = weights.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, G["salt"])
+    net = net.to_empty(device=gpu)
+    net.load_state_dict(sd)
+    del sd
+    net.train()
+    x0, noise, cond, sig = inputs()
+    B, T = G["B"], G["T"]
+    loss_scale = 1024.0
+    A.set_train_dtype(dtype)
+    A.PACK.clear()
+    try:
+        den = TR.TrainDenoiser({"target": "gcd_amd.denoiser_scaling.VScalingWithEDMcNoise"}, use_checkpoint=True)
+        loss_fn = TR.StandardDiffusionLoss(
+            sigma_sampler_config={"target": "gcd_amd.training.EDMSampling", "params": {"p_mean": 1.0, "p_std": 1.6}},
+            loss_weighting_config={"target": "gcd_amd.training.EDMWeighting", "params": {"sigma_data": 1.0}},
+            focus_top=0.1, focus_steps=5000, batch2model_keys=["image_only_indicator", "num_video_frames"])
+        noised = (x0 + noise * sig[:, None, None, None]).to(gpu)
+        sg = sig.to(gpu)
+        out = den(net, noised, sg, {k: v.to(gpu) for k, v in cond.items()}, num_video_frames=T,
+                  image_only_indicator=torch.zeros(B, T, device=gpu))
+        w = loss_fn.loss_weighting(sg)[:, None, None, None]
+        loss = loss_fn.get_loss(out, x0.to(gpu), w, {"global_step": G["step"]}).mean()
+        (loss * loss_scale).backward()
+        torch.cuda.synchronize()
+    finally:
+        A.set_train_dtype("fp16")
+        A.PACK.clear()
+    tol_out, tol_g = (2e-3, 5e-3) if dtype == "fp16" else (1.5e-2, 3e-2)
+    e_out = rel_l2(sample(out.detach().cpu(), 65536), G["out_samples"])
+    print(f"[{dtype}] loss {float(loss):.6f} vs reference {G['loss']:.6f}; denoiser output rel-L2 {e_out:.2e}")
+    assert abs(float(loss) / G["loss"] - 1.0) < (2e-3 if dtype == "fp16" else 1e-2)
+    assert e_out < tol_out
+    num = den_ = 0.0
+    worst_norm, worst = ("", 0.0), ("", 0.0)
+    seen = 0
+    for name, prm in net.named_parameters():
+        if name in G["dead"]:
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, name
+            continue
+        ref_s = G["grad_samples"][name].double()
+        got = prm.grad.detach().float().cpu() / loss_scale
+        got_s = sample(got, 128).double()
+        num += float((got_s - ref_s).pow(2).sum())
+        den_ += float(ref_s.pow(2).sum())
+        seen += 1
+        rn = abs(float(got.double().norm()) / G["grad_norms"][name] - 1.0)
+        if ref_s.numel() >= 64:
+            e = float((got_s - ref_s).norm() / ref_s.norm().clamp_min(1e-30))
+            if e > worst[1]:
+                worst = (name, e)
+            if rn > worst_norm[1]:
+                worst_norm = (name, rn)
+    g_err = (num / den_) ** 0.5
+    print(f"[{dtype}] {seen} parameter gradients: sampled global rel-L2 {g_err:.2e}; worst tensor {worst[0]} {worst[1]:.2e}; "
+          f"worst norm ratio off by {worst_norm[1]:.2e} ({worst_norm[0]})")
+    assert seen == len(G["grad_norms"])
+    assert g_err < tol_g, f"global gradient rel-L2 {g_err:.3e}"
+    assert worst_norm[1] < 4 * tol_g, f"gradient norm of {worst_norm[0]} off by {worst_norm[1]:.3e}"
+    del net
+    torch.cuda.empty_cache()
+
+
 def test_activation_checkpointing_matches(gpu):
     """`use_checkpoint` (True in every GCD config): ResBlocks and transformers re-run on HIP kernels during
     the backward pass — same gradients, less memory held between forward and backward."""

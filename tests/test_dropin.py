@@ -57,6 +57,18 @@ def test_closure_shapes_recovered_or_rejected():
     def scaled(input, sigma, c):                            # does something else: stays generic
         return torch.mul(den(model, input, sigma, c, **extra), 2.0)
 
+    def scaled_input(input, sigma, c):                      # same names, same cells, different arithmetic
+        return den(model, input * 2.0, sigma, c, **extra)
+
+    def swapped(input, sigma, c):                           # arguments reordered
+        return den(model, sigma, input, c, **extra)
+
+    def engine_swapped_roles(input, sigma, c):              # the network where the denoiser belongs
+        return eng.model(eng.denoiser, input, sigma, c, **extra)
+
+    for fn in (scaled_input, swapped, engine_swapped_roles):
+        assert fused_from_closure(fn) is None, fn.__name__
+
     def two_dicts(input, sigma, c):
         return den(model, input, sigma, c, **extra, **other)
     other = {"x": 1}

@@ -84,3 +84,29 @@ def test_calculate_metrics_keys_shapes_and_masks():
     assert md["frame_ssim_vis"][1, 0] == pytest.approx(
         R.masked_ssim(samples[1]["sampled_rgb"][0].astype(np.float64), gt[0].astype(np.float64), vis[0])[1], abs=2e-6)
     assert md["mean_diversity"] > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Pinned to the REFERENCE'S OWN SSIM code: scripts/eval_utils.py:571-666 (masked_ssim, the reference authors'
+# adaptation of skimage 0.22.0's structural_similarity) executed unmodified by oracle/make_golden_metrics.py
+# ---------------------------------------------------------------------------------------------------------------
+def test_ssim_and_masked_ssim_vs_reference_code_golden():
+    from pathlib import Path
+    import torch
+    from gcd_amd import metrics as M
+    from oracle.make_golden_metrics import cases
+    g = torch.load(Path(__file__).resolve().parent / "golden" / "metrics_kat.pt")["values"]
+    seen = 0
+    for name, a, b, m, kw in cases():
+        want = g[name].numpy()
+        got = M.masked_ssim(a, b, m, **kw)
+        tol = 1e-6 if a.dtype == np.float32 else 1e-12
+        assert np.allclose(got, want, rtol=0, atol=tol), (name, got, want)
+        # the un-masked value is what skimage.metrics.structural_similarity returns (test.py:386-420)
+        s = M.structural_similarity(a, b, data_range=1.0, channel_axis=kw.get("channel_axis", 0),
+                                    win_size=kw.get("win_size", 7))
+        assert abs(s - want[0]) <= tol, (name, s, want[0])
+        if name.endswith("_full"):
+            assert abs(want[0] - want[1]) <= 1e-12          # an all-true mask changes nothing
+        seen += 1
+    assert seen == len(g) == 9

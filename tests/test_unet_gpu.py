@@ -396,6 +396,94 @@ def test_sampler_50_steps_pardom_cfg3_vs_reference_golden(gpu):
     torch.cuda.empty_cache()
 
 
+def _loop_vs_reference_golden(gpu, fname):
+    """Run the fused EulerEDM + CFG loop on the inputs of a oracle/make_golden_loop72.py fixture and compare x after
+    the kept steps (65 536 strided samples each) and the full final latents.  Returns (errors per step, final error,
+    final latents, golden)."""
+    from oracle.make_golden_fullres import sample
+    from gcd_amd.sampling import FusedEulerLoop
+    path = GOLD / fname
+    if not path.exists():
+        pytest.skip(f"tests/golden/{fname} has not been generated (python -m oracle.make_golden_loop72)")
+    g = torch.load(path)
+    cfg = getattr(O, g["config"])
+    net, sd = _build(cfg, gpu, salt=g["salt"])
+    del sd
+    T, steps, h, w, first = g["T"], g["steps"], g["h"], g["w"], g["first_step"]
+    noise, c, uc = weights.synth_inputs(1, T, h, w, cfg.context_dim, cfg.adm_in_channels + cfg.aux_emb_dim,
+                                        g["input_seed"])
+    den, model, extra, fused = _stack(net, T, gpu)
+    sampler = _sampler(T, steps, "cuda")
+    loop = FusedEulerLoop(sampler, fused, noise.clone().to(gpu),
+                          {k: v.to(gpu) for k, v in c.items()}, {k: v.to(gpu) for k, v in uc.items()})
+    assert loop.num_steps == steps
+    assert torch.allclose(loop.sigmas.cpu(), g["sigmas"], rtol=1e-6, atol=0)
+    if first:    # the fixture's seeded mid-trajectory state: x = n * sqrt(1 + sigma_first^2)
+        loop.x.copy_((noise * float((1.0 + g["sigmas"][first] ** 2) ** 0.5)).to(gpu))
+    errs = {}
+    with loop:
+        for i in range(first, steps):
+            loop.step(i)
+            if i + 1 in g["trace"]:
+                loop.side.synchronize()
+                errs[i + 1] = rel_l2(sample(loop.x.cpu(), 65536), g["trace"][i + 1]["samples"])
+                nr = float(loop.x.double().norm()) / g["trace"][i + 1]["norm"]
+                assert abs(nr - 1.0) < 1e-3, f"step {i + 1}: norm ratio {nr}"
+    loop.close()
+    e = rel_l2(loop.x, g["final"])
+    z = loop.x.clone()
+    del net, loop
+    torch.cuda.empty_cache()
+    return errs, e, z, g
+
+
+def test_sampler_25_steps_72x128_cfg1_vs_reference_golden(gpu):
+    """BASELINE.json cfg1 AT THE METRIC'S OWN RESOLUTION: the full 25-step EulerEDM + CFG loop of the full-width
+    Kubric network on a 14 x 72 x 128 latent clip against the unmodified reference plugin stack's own fp32
+    trajectory (oracle/make_golden_loop72.py cfg1; ~2 h of CPU time once): every sampled step and the final
+    latents within the loop contract of 1e-3 rel-L2, then frames decoded from both by the HIP VideoDecoder at
+    576 x 1024 compared by PSNR."""
+    errs, e, z, g = _loop_vs_reference_golden(gpu, "loop_kubric_72x128.pt")
+    print("cfg1 72x128 trajectory rel-L2:", {k: f"{v:.2e}" for k, v in errs.items()}, f"final {e:.3e}")
+    assert max(errs.values()) < TOL_LOOP and e < TOL_LOOP, f"25-step loop at 72x128: rel-L2 {e:.3e}"
+    # decoded frames at 576 x 1024 through the HIP first-stage decoder (full 128-channel VideoDecoder, procedural
+    # weights): what a 1e-3 difference of the latents is in pixels
+    import math
+    from gcd_amd.first_stage import decode_first_stage
+    from gcd_amd.temporal_ae import VideoDecoder
+    from oracle import vae_decoder_ref as D
+    with torch.device("meta"):
+        dec = VideoDecoder(**D.KUBRIC.as_reference_kwargs())
+    sdd = weights.synth_state_dict({k: tuple(v.shape) for k, v in dec.state_dict().items()}, salt=1)
+    dec = dec.to_empty(device=gpu)
+    dec.load_state_dict(sdd)
+    dec.eval()
+    frames = decode_first_stage(dec, z, 0.18215, en_and_decode_n_samples_a_time=14).cpu()
+    frames_ref = decode_first_stage(dec, g["final"].to(gpu), 0.18215, en_and_decode_n_samples_a_time=14).cpu()
+    assert frames.shape == (14, 3, 576, 1024)
+    mse = float(((frames.double() - frames_ref.double()) ** 2).mean())
+    psnr = 10.0 * math.log10(4.0 / max(mse, 1e-30))
+    print(f"decoded 576x1024 frames: rel-L2 {rel_l2(frames, frames_ref):.3e}, PSNR {psnr:.1f} dB on the [-1, 1] range")
+    assert psnr >= 55.0
+    del dec
+    torch.cuda.empty_cache()
+
+
+def test_sampler_50_steps_36x64_pardom_cfg3_vs_reference_golden(gpu):
+    """BASELINE.json cfg3: the ParDom network's full 50-step loop at 14 x 36 x 64 against the reference stack."""
+    errs, e, z, g = _loop_vs_reference_golden(gpu, "loop_pardom_36x64.pt")
+    print("cfg3 36x64 trajectory rel-L2:", {k: f"{v:.2e}" for k, v in errs.items()}, f"final {e:.3e}")
+    assert max(errs.values()) < TOL_LOOP and e < TOL_LOOP, f"50-step ParDom loop at 36x64: rel-L2 {e:.3e}"
+
+
+def test_sampler_last_15_of_50_steps_72x128_pardom_cfg3_vs_reference_golden(gpu):
+    """cfg3 at 14 x 72 x 128: the last 15 of the 50 steps (sigma_35 = 1.17 ... 0), where the network term carries the
+    result, from the fixture's seeded mid-trajectory state, against the reference stack."""
+    errs, e, z, g = _loop_vs_reference_golden(gpu, "loop_pardom_72x128_tail.pt")
+    print("cfg3 72x128 tail rel-L2:", {k: f"{v:.2e}" for k, v in errs.items()}, f"final {e:.3e}")
+    assert max(errs.values()) < TOL_LOOP and e < TOL_LOOP, f"ParDom 72x128 tail: rel-L2 {e:.3e}"
+
+
 def test_two_clips_batched_with_image_only_indicator(gpu, tiny):
     """num_samples / batched clips: B = 2 clips in one call (56 frames under CFG: per-clip time_stack
     GroupNorm, per-clip first-frame temporal context, > 32 rows through the small-M kernel), with a
