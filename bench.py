@@ -341,6 +341,14 @@ def main():
         per_rank = [torch.empty_like(elapsed) for _ in range(world)]
         dist.all_gather(per_rank, elapsed)
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    # how many ranks RCCL actually connected: a sum of ones over the nccl (= RCCL) backend, executed, not inferred
+    rccl_ranks = 0
+    if dist is not None and args.backend == "nccl":
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        rccl_ranks = int(one.item())
+        if dist.get_backend() != "nccl" or rccl_ranks != args.gpus:
+            raise SystemExit(f"bench.py: {rccl_ranks} ranks answered over '{dist.get_backend()}' for --gpus {args.gpus}")
     t_gather0 = time.perf_counter()
     gathered = gather_clips(loop.x, dist)             # the one collective of the path
     torch.cuda.synchronize(dev)
@@ -387,7 +395,7 @@ def main():
                              "ms_per_step_median": round(region_ms[len(region_ms) // 2], 3),
                              "reported_region": "first (max over ranks)"},
             "per_rank_ms_per_step": [round(float(t[0]) * 1e3 / args.steps, 3) for t in per_rank],
-            "rccl_ranks": world if (dist is not None and args.backend == "nccl") else 0,
+            "rccl_ranks": rccl_ranks,
             "dist_backend": args.backend if dist is not None else None,
             "gather_ms": round(gather_ms, 3), "gathered_shape": list(gathered.shape),
             "output_finite": finite,

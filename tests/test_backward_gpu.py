@@ -560,9 +560,14 @@ def test_training_step_full_width_cfg4_vs_reference_golden(gpu, dtype):
     num = den_ = 0.0
     worst_norm, worst = ("", 0.0), ("", 0.0)
     seen = 0
+    total_ref = sum(v * v for v in G["grad_norms"].values()) ** 0.5
+    n_dead = 0
     for name, prm in net.named_parameters():
-        if name in G["dead"]:
-            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, name
+        if name in G["dead"] or G["grad_norms"][name] < 1e-7 * total_ref:
+            # to_q / to_k / norm2 of the one-key cross-attentions: exactly zero in exact arithmetic (and here: the
+            # graph never reaches them); the reference's CPU flash kernel leaves rounding noise of ~1e-10 relative
+            assert prm.grad is None or float(prm.grad.double().norm()) / loss_scale < 1e-7 * total_ref, name
+            n_dead += 1
             continue
         ref_s = G["grad_samples"][name].double()
         got = prm.grad.detach().float().cpu() / loss_scale
@@ -580,7 +585,7 @@ def test_training_step_full_width_cfg4_vs_reference_golden(gpu, dtype):
     g_err = (num / den_) ** 0.5
     print(f"[{dtype}] {seen} parameter gradients: sampled global rel-L2 {g_err:.2e}; worst tensor {worst[0]} {worst[1]:.2e}; "
           f"worst norm ratio off by {worst_norm[1]:.2e} ({worst_norm[0]})")
-    assert seen == len(G["grad_norms"])
+    assert seen + n_dead == len(G["grad_norms"]) + len(G["dead"]) and n_dead >= 128
     assert g_err < tol_g, f"global gradient rel-L2 {g_err:.3e}"
     assert worst_norm[1] < 4 * tol_g, f"gradient norm of {worst_norm[0]} off by {worst_norm[1]:.3e}"
     del net

@@ -1,0 +1,69 @@
+"""GPU: the multi-GPU path of the sampler without a multi-GPU node — two ranks, ONE GPU, gloo.
+
+`gcd_amd.parallel.sample_clips` shards clips over the ranks (clip i -> rank i mod world, noise seeded by the clip
+index) and all-gathers the final latents; on an 8-GPU node the ranks sit on 8 GPUs and the backend is nccl (= RCCL
+over xGMI, `bench.py --gpus 8`).  Here both ranks share cuda:0 and talk over gloo, which exercises everything but
+the transport: the real HIP VideoUNet, the fused hipGraph EulerEDM loop, the ragged gather — and the property the
+sharding promises: a clip's result does not depend on how many ranks the job ran on, bit for bit."""
+import pytest
+import torch
+
+import gloo_util
+
+pytestmark = pytest.mark.gpu
+
+
+def _sampler_and_net(dev):
+    from gcd_amd.denoiser import Denoiser
+    from gcd_amd.sampling import EulerEDMSampler, FusedDenoiser
+    from gcd_amd.video_model import VideoUNet
+    from gcd_amd.wrappers import OpenAIWrapper
+    from oracle import svd_unet_ref as O, weights
+    cfg = O.TINY
+    with torch.device("meta"):
+        net = VideoUNet(**cfg.as_reference_kwargs())
+    sd = weights.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    net = net.to_empty(device=dev)
+    net.load_state_dict(sd)
+    net.eval()
+    T = 14
+    sampler = EulerEDMSampler(
+        discretization_config={"target": "gcd_amd.discretizer.EDMDiscretization", "params": {"sigma_max": 700.0}},
+        num_steps=6,
+        guider_config={"target": "gcd_amd.guiders.LinearPredictionGuider",
+                       "params": {"num_frames": T, "max_scale": 1.5, "min_scale": 1.0}},
+        device="cuda")
+    fd = FusedDenoiser(Denoiser({"target": "gcd_amd.denoiser_scaling.VScalingWithEDMcNoise"}), OpenAIWrapper(net),
+                       num_video_frames=T, image_only_indicator=torch.zeros(2, T, device=dev))
+
+    def one(i, g):
+        noise, c, uc = weights.synth_inputs(1, T, 8, 8, cfg.context_dim, cfg.adm_in_channels + cfg.aux_emb_dim, 300 + i)
+        x = torch.randn(noise.shape, generator=g, device=dev)      # the clip's own generator: seed = base + clip index
+        out = sampler(fd, x, cond={k: v.to(dev) for k, v in c.items()}, uc={k: v.to(dev) for k, v in uc.items()})
+        assert sampler.last_path == "fused"
+        return out.cpu()
+    return one
+
+
+def _worker(rank, world, store, num_clips, q):
+    import torch.distributed as dist
+    from gcd_amd import parallel
+    gloo_util.init(rank, world, store)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        one = _sampler_and_net(dev)
+        got = parallel.sample_clips(one, num_clips, dist, base_seed=900, device=dev)
+        ok = len(got) == num_clips and all(t is not None and t.shape == (14, 4, 8, 8) for t in got)
+        if rank == 0:
+            want = parallel.sample_clips(one, num_clips, None, base_seed=900, device=dev)
+            ok = ok and all(torch.equal(a, b) for a, b in zip(got, want))
+            ok = ok and not torch.equal(want[0], want[1])
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_clips", [2, 3])
+def test_two_ranks_one_gpu_fused_loop_equals_single_process(gpu, num_clips):
+    assert gloo_util.run_world(_worker, 2, num_clips, timeout=900) == {0: True, 1: True}
