@@ -85,6 +85,7 @@ SIGNATURES = {
     "gcd_groupnorm_bwd": (_i, [_vp, _i64, _vp, _i64, _i, _i64, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i64, _vp]),
     "gcd_layernorm_bwd": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp, _f, _vp, _i64, _vp, _vp, _vp]),
     "gcd_geglu_fwd_f32": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),
+    "gcd_geglu_fwd_f16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),
     "gcd_geglu_bwd_f32": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _vp]),
     "gcd_softmax_bwd_rows": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _f, _vp]),
     "gcd_attn_spatial_bwd_ws_bytes": (_i64, [_i, _i, _i]),
@@ -94,6 +95,7 @@ SIGNATURES = {
     "gcd_cast_f32_bf16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),
     "gcd_cast_f16_bf16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),
     "gcd_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp]),
+    "gcd_adam_step_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "gcd_graph_begin_capture": (_i, [_vp]),
     "gcd_graph_end_capture": (_i, [_vp, C.POINTER(_vp)]),
     "gcd_graph_launch": (_i, [_vp, _vp]),

@@ -495,13 +495,26 @@ class Fused(torch.autograd.Function):
         kind, geo, norm = spec["kind"], spec.get("geo"), spec.get("norm")
         dt = _dt(FWD_DTYPE)
         stats = g32 = b32 = None
-        if norm is not None:
+        if norm is not None and norm[0] == "geglu":
+            # x is the fp32 projection [value | gate] of a FeedForward (attention.py:87-97): value * gelu(gate),
+            # rounded once to the operand type, straight into the second Linear
+            x = x.contiguous()
+            M, H2 = x.shape
+            y16 = torch.empty(M, H2 // 2, dtype=_f16, device=x.device)
+            check(_lib.load().gcd_geglu_fwd_f16(x.data_ptr(), _ld(x), y16.data_ptr(), _ld(y16), M, H2 // 2,
+                                                _stream()), "gcd_geglu_fwd_f16")
+            a16 = _as_dtype(y16, dt)
+        elif norm is not None:
             x = x.contiguous()
             if norm[0] == "ln":
                 y16, g32 = _ln_fwd(x, gamma, beta, norm[1])
             else:
                 y16, stats, g32, b32 = _gn_fwd(x, gamma, beta, norm[1], norm[2], norm[3])
             a16 = _as_dtype(y16, dt)
+        elif getattr(x, "_gcd_f16", None) is not None and x._gcd_f16[1] == x._version and \
+                x._gcd_f16[0].shape == x.shape:
+            # x is the fp32 image of an fp16 tensor an attention core produced: that tensor IS the operand
+            a16 = _as_dtype(x._gcd_f16[0], dt)
         elif kind == "c3" and _c3_dims(params[0], geo)[2] != x.shape[1]:
             a16 = torch.zeros(x.shape[0], _c3_dims(params[0], geo)[2], dtype=dt, device=x.device)
             _cast16_into(x, a16[:, :x.shape[1]])
@@ -514,7 +527,9 @@ class Fused(torch.autograd.Function):
         ctx.n_params = len(params)
         ctx.has = (residual is not None, rowvec is not None, bias is not None)
         tensors = [a16] + [p for p in params if p is not None]
-        if norm is not None:
+        if norm is not None and norm[0] == "geglu":
+            tensors += [x]
+        elif norm is not None:
             tensors += [x, g32] + ([stats, b32] if norm[0] == "gn" else [])
         ctx.save_for_backward(*tensors)
         return y
@@ -545,6 +560,12 @@ class Fused(torch.autograd.Function):
             dx = da
         elif da is None:
             dx = None
+        elif norm[0] == "geglu":
+            (h,) = saved
+            da = da.contiguous()
+            dx = torch.empty_like(h)
+            check(_lib.load().gcd_geglu_bwd_f32(h.data_ptr(), _ld(h), da.data_ptr(), _ld(da), dx.data_ptr(),
+                                                _ld(dx), h.shape[0], h.shape[1] // 2, _stream()), "gcd_geglu_bwd_f32")
         elif norm[0] == "ln":
             x, g32 = saved
             dx, dgamma, dbeta = _ln_bwd(x, da.contiguous(), g32, norm[1])
@@ -557,10 +578,13 @@ class Fused(torch.autograd.Function):
 
 
 def _fused(kind, x, params, geo=None, norm=None, residual=None, rowvec=None):
-    """norm: None | ("ln", module, eps) | ("gn", module, rows_per_inst, eps, silu); rowvec: (vector [n, N], rows)."""
+    """norm: None | ("ln", module, eps) | ("gn", module, rows_per_inst, eps, silu) | ("geglu",): the prologue applied
+    to x; rowvec: (vector [n, N], rows)."""
     spec = dict(kind=kind, geo=geo, norm=None, rows_per_vec=None if rowvec is None else rowvec[1])
     gamma = beta = None
-    if norm is not None:
+    if norm is not None and norm[0] == "geglu":
+        spec["norm"] = ("geglu",)
+    elif norm is not None:
         gamma, beta = norm[1].weight, norm[1].bias
         spec["norm"] = (norm[0],) + tuple(norm[2:])
     return Fused.apply(spec, x, residual, None if rowvec is None else rowvec[0], gamma, beta, *params)
@@ -685,6 +709,7 @@ class SpatialAttention(torch.autograd.Function):
         ops.attn_spatial(qkv16, vt, S_pad, out16, frames, S, heads, q_prescaled=False)
         ctx.save_for_backward(qkv16, out16)
         ctx.dims = (frames, S, heads)
+        _LAST_F16[0] = out16
         return out16.float()
 
     @staticmethod
@@ -700,8 +725,19 @@ class SpatialAttention(torch.autograd.Function):
         return dqkv, None, None, None
 
 
+_LAST_F16 = [None]
+
+
+def _with_f16(y: torch.Tensor) -> torch.Tensor:
+    """Tag the fp32 result of an attention core with the fp16 tensor it is the image of, so that the Linear that
+    consumes it takes the fp16 tensor as its operand instead of casting the fp32 copy back."""
+    y._gcd_f16 = (_LAST_F16[0], y._version)
+    _LAST_F16[0] = None
+    return y
+
+
 def spatial_attention(qkv, frames, S, heads):
-    return SpatialAttention.apply(qkv, frames, S, heads)
+    return _with_f16(SpatialAttention.apply(qkv, frames, S, heads))
 
 
 class TemporalAttention(torch.autograd.Function):
@@ -718,6 +754,7 @@ class TemporalAttention(torch.autograd.Function):
         ops.attn_temporal(qkv16, out16, clips, T, HW, heads)
         ctx.save_for_backward(qkv16)
         ctx.dims = (clips, T, HW, heads)
+        _LAST_F16[0] = out16
         return out16.float()
 
     @staticmethod
@@ -733,7 +770,7 @@ class TemporalAttention(torch.autograd.Function):
 
 
 def temporal_attention(qkv, clips, T, HW, heads):
-    return TemporalAttention.apply(qkv, clips, T, HW, heads)
+    return _with_f16(TemporalAttention.apply(qkv, clips, T, HW, heads))
 
 
 # ------------------------------------------------------------------------------------------------

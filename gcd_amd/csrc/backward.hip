@@ -393,6 +393,27 @@ __global__ __launch_bounds__(256) void geglu_fwd_kernel(const float* __restrict_
   }
 }
 
+// the same with the result rounded to fp16: the operand of the FeedForward's second Linear, written once
+__global__ __launch_bounds__(256) void geglu_fwd_f16_kernel(const float* __restrict__ h, int64_t ldh,
+                                                            f16* __restrict__ out, int64_t ldo, int64_t M, int H) {
+  const int hv = H >> 3;
+  const int64_t total = M * hv;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t m = idx / hv;
+    const int c = (int)(idx - m * hv) * 8;
+    const float* row = h + m * ldh + c;
+    const f32x4 a0 = *(const f32x4*)row, a1 = *(const f32x4*)(row + 4);
+    const f32x4 g0 = *(const f32x4*)(row + H), g1 = *(const f32x4*)(row + H + 4);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = (f16)(a0[e] * gelu_f(g0[e]));
+      o[e + 4] = (f16)(a1[e] * gelu_f(g1[e]));
+    }
+    *(f16x8*)(out + m * ldo + c) = o;
+  }
+}
+
 __global__ __launch_bounds__(256) void geglu_bwd_kernel(const float* __restrict__ h, int64_t ldh,
                                                         const float* __restrict__ dout, int64_t lddo,
                                                         float* __restrict__ dh, int64_t lddh, int64_t M,
@@ -577,6 +598,42 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// The same step over up to ADAM_MT tensors per launch (the UNet has ~1300 parameter tensors, most of them a few
+// KB: one launch each costs more than their arithmetic).  Block b works on chunk b - first[t] of tensor t.
+constexpr int ADAM_MT = 48;
+constexpr int ADAM_CHUNK = 1 << 16;
+struct AdamMulti {
+  float* p[ADAM_MT];
+  const float* g[ADAM_MT];
+  float* m[ADAM_MT];
+  float* v[ADAM_MT];
+  int64_t n[ADAM_MT];
+  int first[ADAM_MT + 1];   // prefix sum of the tensors' chunk counts
+  int count;
+};
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamMulti a, float lr, float b1, float b2, float eps,
+                                                         float wd, float bc1, float bc2_sqrt, float gscale) {
+  int t = 0;
+  while (t + 1 < a.count && (int)blockIdx.x >= a.first[t + 1]) ++t;
+  const int64_t i0 = (int64_t)((int)blockIdx.x - a.first[t]) * ADAM_CHUNK;
+  const int64_t i1 = i0 + ADAM_CHUNK < a.n[t] ? i0 + ADAM_CHUNK : a.n[t];
+  float* __restrict__ p = a.p[t];
+  const float* __restrict__ g = a.g[t];
+  float* __restrict__ m = a.m[t];
+  float* __restrict__ v = a.v[t];
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    float gi = g[i] * gscale;
+    if (wd != 0.f) gi = fmaf(wd, p[i], gi);
+    const float mi = fmaf(b1, m[i], (1.0f - b1) * gi);
+    const float vi = fmaf(b2, v[i], (1.0f - b2) * gi * gi);
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+
 int grid_for(int64_t work_items) {
   int64_t b = (work_items + 255) / 256;
   if (b > 256 * 32) b = 256 * 32;
@@ -709,6 +766,17 @@ extern "C" int gcd_geglu_fwd_f32(const float* h, int64_t ldh, float* out, int64_
   return 0;
 }
 
+extern "C" int gcd_geglu_fwd_f16(const float* h, int64_t ldh, void* out16, int64_t ldo, int64_t M, int H,
+                                 void* stream) {
+  GCD_CHECK_ARG(h && out16 && M > 0 && H > 0 && H % 8 == 0 && ldh % 4 == 0 && ldo % 8 == 0 &&
+                    (((uintptr_t)h | (uintptr_t)out16) & 15) == 0,
+                "gcd_geglu_fwd_f16: bad args (H=%d must be a multiple of 8)", H);
+  hipLaunchKernelGGL(geglu_fwd_f16_kernel, dim3(grid_for(M * (H / 8))), dim3(256), 0, (hipStream_t)stream, h, ldh,
+                     (f16*)out16, ldo, M, H);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int gcd_geglu_bwd_f32(const float* h, int64_t ldh, const float* dout, int64_t lddo, float* dh,
                                  int64_t lddh, int64_t M, int H, void* stream) {
   GCD_CHECK_ARG(h && dout && dh && M > 0 && H > 0 && H % 4 == 0 && ldh % 4 == 0 && lddo % 4 == 0 && lddh % 4 == 0,
@@ -778,5 +846,40 @@ extern "C" int gcd_adam_step(float* p, const float* g, float* m, float* v, int64
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr,
                      beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
   GCD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gcd_adam_step_multi(int count, float* const* p, const float* const* g, float* const* m,
+                                   float* const* v, const int64_t* n, float lr, float beta1, float beta2,
+                                   float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  GCD_CHECK_ARG(count >= 0 && (count == 0 || (p && g && m && v && n)) && step >= 1, "gcd_adam_step_multi: bad args");
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+  int i = 0;
+  while (i < count) {
+    AdamMulti a;
+    a.count = 0;
+    a.first[0] = 0;
+    // a launch takes up to ADAM_MT tensors and at most ~64 K blocks
+    while (i < count && a.count < ADAM_MT) {
+      GCD_CHECK_ARG(p[i] && g[i] && m[i] && v[i] && n[i] >= 0, "gcd_adam_step_multi: tensor %d: null pointer", i);
+      const int64_t chunks = (n[i] + ADAM_CHUNK - 1) / ADAM_CHUNK;
+      if (a.count > 0 && a.first[a.count] + chunks > 65535) break;
+      GCD_CHECK_ARG(chunks < (1ll << 30), "gcd_adam_step_multi: tensor %d too large", i);
+      a.p[a.count] = p[i];
+      a.g[a.count] = g[i];
+      a.m[a.count] = m[i];
+      a.v[a.count] = v[i];
+      a.n[a.count] = n[i];
+      a.first[a.count + 1] = a.first[a.count] + (int)chunks;
+      ++a.count;
+      ++i;
+    }
+    if (a.first[a.count] > 0) {
+      hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)a.first[a.count]), dim3(256), 0, (hipStream_t)stream, a,
+                         lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+      GCD_CHECK_LAUNCH();
+    }
+  }
   return 0;
 }

@@ -454,7 +454,9 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
   bool use_pp = false;
   if (impl != 1 && impl != 5 && impl != 6 && gcd_gemm_pp_supported(k, d->mode)) {
     const int64_t tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 319) / 320);
-    use_pp = (impl >= 2 && impl != 7) || ((impl == 0 || impl == 7) && tiles >= 192 && d->N >= 160);
+    int min_tiles = gcd_tune_get(GCD_TUNE_PP_MIN_TILES);
+    if (min_tiles <= 0) min_tiles = 192;
+    use_pp = (impl >= 2 && impl != 7) || ((impl == 0 || impl == 7) && tiles >= min_tiles && d->N >= 160);
     // K (or the channels per tap) a multiple of 32 but not of 64: only the ping-pong kernel's 32-deep
     // sub-tiles can walk it
     if (d->K % 64 != 0 || (d->mode != GCD_GEMM_PLAIN && d->Cin % 64 != 0)) use_pp = true;
@@ -549,7 +551,9 @@ extern "C" int gcd_gemm_colstats_supported(const gcd_gemm_desc* d) {
   const int impl = gcd_tune_get(GCD_TUNE_GEMM_IMPL);
   if (impl == 1 || impl == 5 || impl == 6) return 0;          // general kernel forced
   const int64_t tiles = (int64_t)(d->M / 256) * (d->N / 320);
-  if ((impl == 0 || impl == 7) && tiles < 192) return 0;      // automatic choice: general kernel / split-K
+  int min_tiles = gcd_tune_get(GCD_TUNE_PP_MIN_TILES);
+  if (min_tiles <= 0) min_tiles = 192;
+  if ((impl == 0 || impl == 7) && tiles < min_tiles) return 0;      // automatic choice: general kernel / split-K
   return 1;
 }
 

@@ -196,7 +196,9 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mod
         d.workspace, d.workspace_bytes = sk.data_ptr(), sk.numel() * sk.element_size()
     expect = torch.float32 if out_kind == OUT_F32 else torch.float16
     assert out.dtype == expect, f"out dtype {out.dtype} does not match out_kind {out_kind}"
-    with _Timed("gemm", 2.0 * M * N * K * alg_flops_scale, M=M, N=N, K=K, mode=mode):
+    with _Timed("gemm", 2.0 * M * N * K * alg_flops_scale, M=M, N=N, K=K, mode=mode, out_kind=out_kind,
+                nres=int(r1 is not None) + int(r2 is not None), cin=(conv or {}).get("Cin", K),
+                stride=(conv or {}).get("stride", 1), up=int((conv or {}).get("upsample", 0))):
         check(_lib.load().gcd_gemm_f16(C.byref(d), _stream()), "gcd_gemm_f16")
     return out
 

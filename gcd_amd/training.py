@@ -136,7 +136,7 @@ def _cross_attention_one_key(att, ctx_rows: torch.Tensor) -> torch.Tensor:
 
 def _ff(ff, x, norm=None, residual=None):
     h = A.linear(x, ff.net[0].proj.weight, ff.net[0].proj.bias, norm=norm)
-    return A.linear(A.geglu(h), ff.net[2].weight, ff.net[2].bias, residual=residual)
+    return A.linear(h, ff.net[2].weight, ff.net[2].bias, norm=("geglu",), residual=residual)
 
 
 def _ln(m):
@@ -374,7 +374,11 @@ class AdamHIP:
 
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0):
+        import ctypes as C
+        from . import _lib
         self.step_count += 1
+        ps, gs, ms, vs = [], [], [], []
+        keep = []
         for p, (m, v) in zip(self.params, self.state):
             if p.grad is None:
                 # A trainable parameter the graph never reached (attn2.to_q / to_k / norm2 behind the one-key
@@ -386,10 +390,23 @@ class AdamHIP:
                 g = torch.zeros_like(p, dtype=torch.float32)
             else:
                 g = p.grad.detach().float().contiguous()
+            assert p.is_contiguous() and p.dtype == torch.float32
             self._touched[id(p)] = True
-            A.adam_step(p.data, g, m, v, self.step_count, self.lr, self.betas, self.eps, self.weight_decay,
-                        grad_scale)
-        # gcd_adam_step writes the parameters through raw pointers, which torch's version counters do
+            keep.append(g)
+            ps.append(p.data)
+            gs.append(g)
+            ms.append(m)
+            vs.append(v)
+        n = len(ps)
+        if n:
+            ops._need_gpu(*ps[:1], *gs[:1])
+            arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])      # noqa: E731
+            numel = (C.c_int64 * n)(*[t.numel() for t in ps])
+            _lib.check(_lib.load().gcd_adam_step_multi(
+                n, arr(ps), arr(gs), arr(ms), arr(vs), numel, self.lr, self.betas[0], self.betas[1], self.eps,
+                self.weight_decay, self.step_count, grad_scale, torch.cuda.current_stream().cuda_stream),
+                "gcd_adam_step_multi")
+        # gcd_adam_step_multi writes the parameters through raw pointers, which torch's version counters do
         # not see: drop the fp16 operand forms that were packed from the old values
         A.PACK.clear()
 

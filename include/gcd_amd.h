@@ -43,10 +43,13 @@ int gcd_device_info(int device, char* name, int cap, int* num_cus, size_t* hbm_b
  *   GCD_TUNE_GEMM_IMPL: 0 = automatic, 1 = general 128-row kernel, 2 = 256x320 ping-pong kernel,
  *                       4 = ping-pong kernel, never persistent; 5 / 6 = general kernel, never / always
  *                       64-row tiles; 7 = like 0 (split-K allowed, used by tests); >= 32: ablation builds
- *   GCD_TUNE_ATTN_IMPL: 0 = automatic, other values select spatial-attention kernel variants   */
+ *   GCD_TUNE_ATTN_IMPL: 0 = automatic, other values select spatial-attention kernel variants
+ *   GCD_TUNE_PP_MIN_TILES: automatic GEMM choice takes the ping-pong kernel from this many 256x320 tiles
+ *                       (0 = the default, 192; environment GCD_PP_MIN_TILES)                   */
 #define GCD_TUNE_GEMM_IMPL 0
 #define GCD_TUNE_ATTN_IMPL 1
-#define GCD_TUNE_COUNT 2
+#define GCD_TUNE_PP_MIN_TILES 2
+#define GCD_TUNE_COUNT 3
 int gcd_tune_set(int knob, int value);
 
 /* ---- GEMM family (Linear / Conv2d 3x3 / Conv2d 1x1 / Conv3d (3,1,1) as implicit GEMM) ------ */
@@ -313,6 +316,8 @@ int gcd_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy
 /* GEGLU on the fp32 projection h = [value | gate] [M, 2H] (attention.py:87-97): out = value*gelu(gate)
  * (exact erf) and its backward.                                                                      */
 int gcd_geglu_fwd_f32(const float* h, int64_t ldh, float* out, int64_t ldo, int64_t M, int H, void* stream);
+/* the forward with the result rounded to fp16 (the operand of FeedForward's second Linear, written once)  */
+int gcd_geglu_fwd_f16(const float* h, int64_t ldh, void* out16, int64_t ldo, int64_t M, int H, void* stream);
 int gcd_geglu_bwd_f32(const float* h, int64_t ldh, const float* dout, int64_t lddo, float* dh, int64_t lddh,
                       int64_t M, int H, void* stream);
 /* Softmax backward over R rows of S scores: dS16 = P16 * (dP - rowsum(P16*dP)) * scale.              */
@@ -341,6 +346,11 @@ int gcd_cast_scale_f32_f16(const float* x, int64_t ldx, void* y16, int64_t ldy, 
  * multiplied into g first (1 / loss_scale, 1 / world_size ...).  diffusion.py:412-431.                */
 int gcd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* The same step for `count` tensors (HOST arrays of device pointers / element counts) in as few launches as
+ * 48 tensors / 64 K chunks of 64 K elements each allow: the ~1300 parameter tensors of the UNet in ~30 launches. */
+int gcd_adam_step_multi(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
+                        const int64_t* n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                        int step, float grad_scale, void* stream);
 
 /* ---- stream / graph plumbing ---------------------------------------------------------------- */
 int gcd_graph_begin_capture(void* stream);

@@ -1,0 +1,35 @@
+#!/bin/bash
+# tools/collect_profiles.sh TAG — everything profiles/TAG_* is made from, in one pass on the GPU box (from the repo
+# root): the bench line, the rocprofv3 kernel trace of the same command, the PMC traffic / SQ passes (one counter
+# group per pass, --kernel-trace only), the per-shape GEMM tables, the fine-tune step.  Outputs under gpurun_out/TAG/.
+TAG=${1:-prof}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/trace -o p -- python $ROOT/bench.py --steps 5 --warmup 2 \
+    --repeats 1 --no-cpu-baseline > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err)
+python tools/rocpd_stats.py $(find $OUT/trace -name "*_results.db" | head -1) --steps 8 > $OUT/kernel_stats.txt
+for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+  D=$OUT/pmc_${C%% *}
+  (cd /tmp && rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -o p -- python $ROOT/bench.py --steps 1 \
+      --warmup 1 --repeats 1 --no-cpu-baseline --dump-profile $OUT/launches.json > $D.log 2>&1)
+done
+F=$(find $OUT/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
+W=$(find $OUT/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+H=$(find $OUT/pmc_TCC_HIT_sum -name "*counter_collection.csv" | head -1)
+python tools/pmc_traffic.py $F $W --json $OUT/hbm_traffic.json --source profiles/${TAG}_hbm_traffic.txt > $OUT/hbm_traffic.txt
+python tools/pmc_gemm_shapes.py $OUT/launches.json $F $W $H > $OUT/gemm_shape_traffic.txt
+(cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU \
+    SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
+    -d $OUT/pmc_sq -o p -- python $ROOT/bench.py --steps 1 --warmup 1 --repeats 1 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1)
+(cd tools && python pmc_sq.py $(find $OUT/pmc_sq -name "*counter_collection.csv" | head -1) > $OUT/sq_counters.txt)
+tools/gemm_bench full 5 > $OUT/gemm_bench_rows.txt 2>&1
+for dt in fp16 bf16; do python tools/train_step_bench.py --steps 3 --dtype $dt > $OUT/train_step_$dt.json 2>/dev/null; done
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/trace_train -o t -- python $ROOT/tools/train_step_bench.py --steps 2 \
+    > /dev/null 2>&1)
+python tools/rocpd_stats.py $(find $OUT/trace_train -name "*_results.db" | head -1) > $OUT/train_kernel_stats.txt
+find $OUT -name "*.db" -delete
+find $OUT -name "*counter_collection.csv" -size +20M -delete
+ls -la $OUT
