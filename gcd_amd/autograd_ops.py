@@ -511,7 +511,7 @@ class Fused(torch.autograd.Function):
             else:
                 y16, stats, g32, b32 = _gn_fwd(x, gamma, beta, norm[1], norm[2], norm[3])
             a16 = _as_dtype(y16, dt)
-        elif getattr(x, "_gcd_f16", None) is not None and x._gcd_f16[1] == x._version and \
+        elif _F16_PASSTHROUGH and getattr(x, "_gcd_f16", None) is not None and x._gcd_f16[1] == x._version and \
                 x._gcd_f16[0].shape == x.shape:
             # x is the fp32 image of an fp16 tensor an attention core produced: that tensor IS the operand
             a16 = _as_dtype(x._gcd_f16[0], dt)
@@ -726,6 +726,10 @@ class SpatialAttention(torch.autograd.Function):
 
 
 _LAST_F16 = [None]
+# Off by default: measured (same box, interleaved; profiles/r03b_train_ab.txt) the step is 5 ms SLOWER with it — the
+# forward's 16 attention outputs go through one cast less, but holding the fp16 tensors through the fp32 edge's
+# lifetime costs more than the casts save.
+_F16_PASSTHROUGH = os.environ.get("GCD_TRAIN_F16_PASSTHROUGH", "0") != "0"
 
 
 def _with_f16(y: torch.Tensor) -> torch.Tensor:

@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // The same step over up to ADAM_MT tensors per launch (the UNet has ~1300 parameter tensors, most of them a few
 // KB: one launch each costs more than their arithmetic).  Block b works on chunk b - first[t] of tensor t.
 constexpr int ADAM_MT = 48;
-constexpr int ADAM_CHUNK = 1 << 16;
+constexpr int ADAM_CHUNK = 1 << 14;   // 16 float4 per thread: 4 x 64 KB in flight per block
 struct AdamMulti {
   float* p[ADAM_MT];
   const float* g[ADAM_MT];
@@ -622,16 +622,39 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamMulti a, floa
   const float* __restrict__ g = a.g[t];
   float* __restrict__ m = a.m[t];
   float* __restrict__ v = a.v[t];
-  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-    float gi = g[i] * gscale;
-    if (wd != 0.f) gi = fmaf(wd, p[i], gi);
-    const float mi = fmaf(b1, m[i], (1.0f - b1) * gi);
-    const float vi = fmaf(b2, v[i], (1.0f - b2) * gi * gi);
-    m[i] = mi;
-    v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] -= (lr / bc1) * (mi / denom);
+  const float step = lr / bc1, omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+  auto upd = [&](float& pi, float gi, float& mi, float& vi) {
+    gi *= gscale;
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    mi = fmaf(b1, mi, omb1 * gi);
+    vi = fmaf(b2, vi, omb2 * gi * gi);
+    pi -= step * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  };
+  // 16-byte vectors where all four bases are 16-byte aligned (torch allocations are); chunks start at multiples
+  // of 16 K elements, so only the tensor's last few elements take the scalar path
+  const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+  int64_t i = i0;
+  if (vec) {
+    const int64_t nv = (i1 - i0) >> 2;
+    for (int64_t k = threadIdx.x; k < nv; k += 256) {
+      const int64_t j = i0 + 4 * k;
+      f32x4 pv = *(f32x4*)(p + j), mv = *(f32x4*)(m + j), vv = *(f32x4*)(v + j);
+      const f32x4 gv = *(const f32x4*)(g + j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float pe = pv[e], me = mv[e], ve = vv[e];
+        upd(pe, gv[e], me, ve);
+        pv[e] = pe;
+        mv[e] = me;
+        vv[e] = ve;
+      }
+      *(f32x4*)(p + j) = pv;
+      *(f32x4*)(m + j) = mv;
+      *(f32x4*)(v + j) = vv;
+    }
+    i = i0 + 4 * nv;
   }
+  for (i += threadIdx.x; i < i1; i += 256) upd(p[i], g[i], m[i], v[i]);
 }
 
 int grid_for(int64_t work_items) {

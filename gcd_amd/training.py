@@ -25,6 +25,7 @@ torch.autograd on the CPU oracle); nothing here is on the measured inference pat
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Iterable, List, Optional
 
 import torch
@@ -134,8 +135,14 @@ def _cross_attention_one_key(att, ctx_rows: torch.Tensor) -> torch.Tensor:
     return A.linear(A.linear(ctx_rows, att.to_v.weight, None), att.to_out[0].weight, att.to_out[0].bias)
 
 
+_GEGLU_PROLOGUE = os.environ.get("GCD_TRAIN_GEGLU_PROLOGUE", "1") != "0"
+_ADAM_MULTI = os.environ.get("GCD_ADAM_MULTI", "1") != "0"
+
+
 def _ff(ff, x, norm=None, residual=None):
     h = A.linear(x, ff.net[0].proj.weight, ff.net[0].proj.bias, norm=norm)
+    if not _GEGLU_PROLOGUE:      # A/B switch: GEGLU as its own graph node with an fp32 result
+        return A.linear(A.geglu(h), ff.net[2].weight, ff.net[2].bias, residual=residual)
     return A.linear(h, ff.net[2].weight, ff.net[2].bias, norm=("geglu",), residual=residual)
 
 
@@ -367,6 +374,7 @@ class AdamHIP:
                       for p in self.params]
         self.step_count = 0
         self._touched = {}       # id(p) -> the moments of p have been written at least once
+        self._tables = None      # cached ctypes pointer tables of (params, m, v)
 
     def zero_grad(self):
         for p in self.params:
@@ -398,12 +406,19 @@ class AdamHIP:
             ms.append(m)
             vs.append(v)
         n = len(ps)
-        if n:
+        if n and not _ADAM_MULTI:          # A/B switch: one launch per tensor
+            for p_, g_, m_, v_ in zip(ps, gs, ms, vs):
+                A.adam_step(p_, g_, m_, v_, self.step_count, self.lr, self.betas, self.eps, self.weight_decay, grad_scale)
+        elif n:
             ops._need_gpu(*ps[:1], *gs[:1])
             arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])      # noqa: E731
-            numel = (C.c_int64 * n)(*[t.numel() for t in ps])
+            # parameter / moment addresses do not change between steps: their pointer tables are built once
+            key = tuple(id(t) for t in ps)
+            if self._tables is None or self._tables[0] != key:
+                self._tables = (key, arr(ps), arr(ms), arr(vs), (C.c_int64 * n)(*[t.numel() for t in ps]))
+            _, ap, am, av, numel = self._tables
             _lib.check(_lib.load().gcd_adam_step_multi(
-                n, arr(ps), arr(gs), arr(ms), arr(vs), numel, self.lr, self.betas[0], self.betas[1], self.eps,
+                n, ap, arr(gs), am, av, numel, self.lr, self.betas[0], self.betas[1], self.eps,
                 self.weight_decay, self.step_count, grad_scale, torch.cuda.current_stream().cuda_stream),
                 "gcd_adam_step_multi")
         # gcd_adam_step_multi writes the parameters through raw pointers, which torch's version counters do

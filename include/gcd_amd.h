@@ -347,7 +347,7 @@ int gcd_cast_scale_f32_f16(const float* x, int64_t ldx, void* y16, int64_t ldy, 
 int gcd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 /* The same step for `count` tensors (HOST arrays of device pointers / element counts) in as few launches as
- * 48 tensors / 64 K chunks of 64 K elements each allow: the ~1300 parameter tensors of the UNet in ~30 launches. */
+ * 48 tensors / 64 K chunks of 16 K elements each allow: the ~1300 parameter tensors of the UNet in ~30 launches. */
 int gcd_adam_step_multi(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
                         const int64_t* n, float lr, float beta1, float beta2, float eps, float weight_decay,
                         int step, float grad_scale, void* stream);

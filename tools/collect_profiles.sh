@@ -25,6 +25,10 @@ python tools/pmc_gemm_shapes.py $OUT/launches.json $F $W $H > $OUT/gemm_shape_tr
     SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
     -d $OUT/pmc_sq -o p -- python $ROOT/bench.py --steps 1 --warmup 1 --repeats 1 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1)
 (cd tools && python pmc_sq.py $(find $OUT/pmc_sq -name "*counter_collection.csv" | head -1) > $OUT/sq_counters.txt)
+(cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_MFMA \
+    SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_LDS --kernel-trace --output-format csv \
+    -d $OUT/pmc_sq2 -o p -- python $ROOT/bench.py --steps 1 --warmup 1 --repeats 1 --no-cpu-baseline > $OUT/pmc_sq2.log 2>&1)
+(cd tools && python pmc_sq2.py $(find $OUT/pmc_sq2 -name "*counter_collection.csv" | head -1) > $OUT/sq_valu_mix.txt)
 tools/gemm_bench full 5 > $OUT/gemm_bench_rows.txt 2>&1
 for dt in fp16 bf16; do python tools/train_step_bench.py --steps 3 --dtype $dt > $OUT/train_step_$dt.json 2>/dev/null; done
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/trace_train -o t -- python $ROOT/tools/train_step_bench.py --steps 2 \
