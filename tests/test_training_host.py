@@ -113,3 +113,53 @@ def test_allreduce_single_process_is_noop():
     p = torch.nn.Parameter(torch.zeros(3))
     p.grad = torch.ones(3)
     assert allreduce_gradients([p], None) == 0 and torch.equal(p.grad, torch.ones(3))
+
+
+# ------------------------------------------------------------------------------- packed-operand cache
+def test_pack_cache_registry_semantics():
+    """autograd_ops._PackCache caches packed operands ONLY for parameters of attached modules (looked up by address,
+    verified against the still-alive owner), never for temporaries — whose addresses the allocator recycles."""
+    from gcd_amd.autograd_ops import _PackCache
+    pc = _PackCache()
+    lin = torch.nn.Linear(8, 4)
+    calls = []
+
+    def pack(w):
+        calls.append(1)
+        return w.detach().clone()
+
+    # un-attached: packed every time, nothing kept
+    pc.get(lin.weight, "k", pack)
+    pc.get(lin.weight, "k", pack)
+    assert len(calls) == 2 and not pc._d
+    pc.attach(lin)
+    a = pc.get(lin.weight, "k", pack)
+    b = pc.get(lin.weight, "k", pack)
+    assert a is b and len(calls) == 3
+    # a detached alias (what non-reentrant checkpointing hands the backward pass) and a reshaped view hit the entry
+    assert pc.get(lin.weight.detach(), "k", pack) is a and pc.get(lin.weight.view(2, 16), "k", pack) is a
+    # an in-place update bumps the version: repacked
+    with torch.no_grad():
+        lin.weight.add_(1.0)
+    c = pc.get(lin.weight, "k", pack)
+    assert c is not a and torch.equal(c, lin.weight)
+    # a temporary of the same shape is never cached, and never served from the parameter's entry
+    t = torch.zeros(4, 8)
+    d = pc.get(t, "k", pack)
+    assert torch.equal(d, t) and len(pc._d) == 1
+    # several parameters packed together: cached on all of them
+    lin2 = torch.nn.Linear(8, 4)
+    pc.attach(lin2)
+    m1 = pc.get_multi((lin.weight, lin2.weight), "cat", lambda ws: torch.cat(ws, 0))
+    m2 = pc.get_multi((lin.weight, lin2.weight), "cat", lambda ws: torch.cat(ws, 0))
+    assert m1 is m2 and m1.shape == (8, 8)
+    assert pc.get_multi((lin.weight, t), "cat", lambda ws: torch.cat(ws, 0)) is not \
+        pc.get_multi((lin.weight, t), "cat", lambda ws: torch.cat(ws, 0))
+    # the owner dies: its address is no longer trusted
+    ptr = lin2.weight.data_ptr()
+    del lin2
+    import gc
+    gc.collect()
+    assert pc._reg[ptr]() is None
+    pc.clear()
+    assert not pc._d

@@ -82,7 +82,8 @@ def main():
         f2, w = 2 * g["fetch"] / n, g["write"] / n
         us = g["ms"] / n * 1e3
         hit = g["hit"] / max(g["hit"] + g["miss"], 1.0) if tcc else float("nan")
-        kern = g["kernel"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[:44]
+        kern = " + ".join(k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                          for k in g["kernel"].split(" + "))[:56]
         print(f"{M:7d} {N:6d} {K:6d} {mode:4d} {ok:3d} {nres:3d} {n:5d} {us:8.1f} {2.0 * M * N * K / us / 1e6:7.0f} {f2:11.1f} "
               f"{alg_r:9.1f} {f2 / alg_r:6.2f} {w:9.1f} {alg_w:9.1f} {hit:7.3f}  {kern}")
         tot["f"] += f2 * n
