@@ -6,8 +6,9 @@ cores, ≈16 GiB RSS), so every job checkpoints its state under /tmp and resumes
 
   python -m oracle.make_golden_loop72 cfg1      BASELINE.json cfg1: Kubric net, the full 25-step loop at
                                                 14 x 72 x 128                  -> loop_kubric_72x128.pt
-  python -m oracle.make_golden_loop72 cfg3mid   cfg3: ParDom net, the full 50-step loop at 14 x 36 x 64
-                                                                               -> loop_pardom_36x64.pt
+  python -m oracle.make_golden_loop72 cfg3mid   cfg3: ParDom net, the full 50-step loop at 14 x 40 x 64
+                                                (latent sides must be multiples of 8: three stride-2 levels)
+                                                                               -> loop_pardom_40x64.pt
   python -m oracle.make_golden_loop72 cfg3tail  cfg3: ParDom net at 14 x 72 x 128, the LAST 15 of the 50
                                                 steps (sigma_35 = 1.17 .. 0: where the network term carries
                                                 the result) from a seeded mid-trajectory state
@@ -38,7 +39,7 @@ OUT = ROOT / "tests" / "golden"
 JOBS = {
     #            config    salt seed  h   w   steps first keep                              file
     "cfg1":     ("KUBRIC", 2,   181, 72, 128, 25,   0,    (1, 5, 10, 15, 20, 25),           "loop_kubric_72x128.pt"),
-    "cfg3mid":  ("PARDOM", 3,   193, 36, 64,  50,   0,    (1, 10, 20, 30, 40, 45, 50),      "loop_pardom_36x64.pt"),
+    "cfg3mid":  ("PARDOM", 3,   193, 40, 64,  50,   0,    (1, 10, 20, 30, 40, 45, 50),      "loop_pardom_40x64.pt"),
     "cfg3tail": ("PARDOM", 3,   194, 72, 128, 50,   35,   (36, 38, 40, 42, 44, 46, 48, 50), "loop_pardom_72x128_tail.pt"),
 }
 

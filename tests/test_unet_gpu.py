@@ -469,11 +469,11 @@ def test_sampler_25_steps_72x128_cfg1_vs_reference_golden(gpu):
     torch.cuda.empty_cache()
 
 
-def test_sampler_50_steps_36x64_pardom_cfg3_vs_reference_golden(gpu):
-    """BASELINE.json cfg3: the ParDom network's full 50-step loop at 14 x 36 x 64 against the reference stack."""
-    errs, e, z, g = _loop_vs_reference_golden(gpu, "loop_pardom_36x64.pt")
-    print("cfg3 36x64 trajectory rel-L2:", {k: f"{v:.2e}" for k, v in errs.items()}, f"final {e:.3e}")
-    assert max(errs.values()) < TOL_LOOP and e < TOL_LOOP, f"50-step ParDom loop at 36x64: rel-L2 {e:.3e}"
+def test_sampler_50_steps_40x64_pardom_cfg3_vs_reference_golden(gpu):
+    """BASELINE.json cfg3: the ParDom network's full 50-step loop at 14 x 40 x 64 against the reference stack."""
+    errs, e, z, g = _loop_vs_reference_golden(gpu, "loop_pardom_40x64.pt")
+    print("cfg3 40x64 trajectory rel-L2:", {k: f"{v:.2e}" for k, v in errs.items()}, f"final {e:.3e}")
+    assert max(errs.values()) < TOL_LOOP and e < TOL_LOOP, f"50-step ParDom loop at 40x64: rel-L2 {e:.3e}"
 
 
 def test_sampler_last_15_of_50_steps_72x128_pardom_cfg3_vs_reference_golden(gpu):
