@@ -114,6 +114,7 @@ def _t16_padded(x16: torch.Tensor, granule: int = 64) -> torch.Tensor:
     return out
 
 
+_FUSE_DY_SUMS = os.environ.get("GCD_TRAIN_FUSE_DY_SUMS", "1") != "0"      # A/B switch
 _WS = {}
 
 
@@ -144,7 +145,21 @@ def _gemm(a16, w16, out, **kw):
     return ops.gemm(a16, w16, out, operand_bf16=a16.dtype == _bf16, workspace=_train_ws(a16.device), **kw)
 
 
-def _grad_contractions(dy32: torch.Tensor, x16: torch.Tensor, w_t16, need_dx: bool, need_dw: bool):
+def _cast16_colsum(dy32: torch.Tensor, dtype: torch.dtype, rows_per_block: Optional[int]):
+    """(dy16, sums [M / rows, N]): the incoming gradient rounded for the GEMMs and its row-block column sums (bias /
+    per-frame-vector gradients) in one pass (gcd_cast_colsum_f32); plain cast when no sums are wanted or the width
+    is not a multiple of 8."""
+    M, N = dy32.shape
+    if rows_per_block is None or N % 8:
+        return _cast16(dy32, dtype), (None if rows_per_block is None else _colsum(dy32, rows_per_block))
+    y = torch.empty(M, N, dtype=dtype, device=dy32.device)
+    sums = torch.zeros(M // rows_per_block, N, dtype=_f32, device=dy32.device)
+    check(_lib.load().gcd_cast_colsum_f32(dy32.data_ptr(), _ld(dy32), y.data_ptr(), _ld(y), M, N, rows_per_block,
+                                          sums.data_ptr(), int(dtype == _bf16), _stream()), "gcd_cast_colsum_f32")
+    return y, sums
+
+
+def _grad_contractions(dy32: torch.Tensor, x16: torch.Tensor, w_t16, need_dx: bool, need_dw: bool, dy16=None):
     """The two contractions every Linear-shaped backward needs, on gcd_gemm_f16:
          dX [M, K] = dY [M, N] @ W [N, K]      (w_t16() -> W^T, [K, N], in the backward operand type)
          dW [N, K] = dY^T [N, M] @ X [M, K]    (x16 [M, K]; split-K over the tokens)
@@ -152,7 +167,8 @@ def _grad_contractions(dy32: torch.Tensor, x16: torch.Tensor, w_t16, need_dx: bo
     M, N = dy32.shape
     dev = dy32.device
     dt = _dt(GRAD_DTYPE)
-    dy16 = _cast16(dy32, dt)
+    if dy16 is None:
+        dy16 = _cast16(dy32, dt)
     dx = dw = None
     if need_dx:
         wt = w_t16(dt)
@@ -344,25 +360,31 @@ def _contract_fwd(kind, a16, params, geo, bias_vec_res):
     raise ValueError(kind)
 
 
-def _contract_bwd(kind, dy, a16, params, geo, need_da, need_dw):
-    """dy fp32 contiguous -> (da fp32 | None, [parameter gradients in the order of `params`, bias included])."""
+def _contract_bwd(kind, dy, a16, params, geo, need_da, need_dw, dy16=None, db_pre=None):
+    """dy fp32 contiguous -> (da fp32 | None, [parameter gradients in the order of `params`, bias included]).
+    dy16 / db_pre: the gradient already rounded to the backward operand type and its column sums (the bias gradient),
+    when the caller produced them in one pass."""
     dev = dy.device
     dt = _dt(GRAD_DTYPE)
     lib = _lib.load()
+
+    def bias_grad(bias, wanted):
+        if bias is None or not wanted:
+            return None
+        return db_pre if db_pre is not None else _colsum(dy)[0]
     if kind == "lin":
         weight, bias = params
         da, dw = _grad_contractions(dy, a16, lambda d: PACK.get(weight, f"lin_t_{d}", _pack_lin_t(d)),
-                                    need_da, need_dw[0])
+                                    need_da, need_dw[0], dy16)
         if dw is not None:
             dw = dw.reshape(weight.shape)
-        db = _colsum(dy)[0] if bias is not None and need_dw[1] else None
-        return da, [dw, db]
+        return da, [dw, bias_grad(bias, need_dw[1])]
     if kind == "qkv":
         da, dw = _grad_contractions(
             dy, a16,
             lambda d: PACK.get_multi(params, f"qkv_t_{d}",
                                      lambda ws: torch.cat([w.t().to(d) for w in ws], 1).contiguous()),
-            need_da, any(need_dw))
+            need_da, any(need_dw), dy16)
         if dw is None:
             return da, [None, None, None]
         n = params[0].shape[0]
@@ -372,11 +394,12 @@ def _contract_bwd(kind, dy, a16, params, geo, need_da, need_dw):
         Cin, Cout, cin_p, cout_p = _c3_dims(weight, geo)
         frames, Hi, Wi, Ho, Wo = geo["frames"], geo["Hi"], geo["Wi"], geo["Ho"], geo["Wo"]
         Mout, Min = frames * Ho * Wo, frames * Hi * Wi
-        dyp = dy
         if cout_p != Cout:
             dyp = torch.zeros(Mout, cout_p, dtype=_f32, device=dev)
             dyp[:, :Cout] = dy
-        dy16 = _cast16(dyp, dt)
+            dy16 = _cast16(dyp, dt)
+        elif dy16 is None:
+            dy16 = _cast16(dy, dt)
         da = dw = None
         if need_da and geo["stride"] == 1:
             # dgrad as an implicit-GEMM convolution of dY on the forward kernel (no dcol tensor, no col2im),
@@ -408,13 +431,13 @@ def _contract_bwd(kind, dy, a16, params, geo, need_da, need_dw):
             dwp = torch.empty(cout_p, 9 * cin_p, dtype=_f32, device=dev)
             _gemm(_t16_padded(dy16), _t16_padded(col), dwp, M=cout_p)       # dW = dY^T col, split-K over the tokens
             dw = dwp.reshape(cout_p, 3, 3, cin_p).permute(0, 3, 1, 2)[:Cout, :Cin].contiguous()
-        db = _colsum(dy)[0] if bias is not None and need_dw[1] else None
-        return da, [dw, db]
+        return da, [dw, bias_grad(bias, need_dw[1])]
     if kind == "t3":
         weight, bias = params
         M, Cc = a16.shape
         Cout = weight.shape[0]
-        dy16 = _cast16(dy, dt)
+        if dy16 is None:
+            dy16 = _cast16(dy, dt)
         da = dw = None
         if need_da:
             wd = PACK.get(weight, f"t3d_{dt}", _pack_t3_dgrad(dt))          # [Cin, 3*Cout]
@@ -428,8 +451,7 @@ def _contract_bwd(kind, dy, a16, params, geo, need_da, need_dw):
             dwp = torch.empty(Cout, 3 * Cc, dtype=_f32, device=dev)
             _gemm(_t16_padded(dy16), _t16_padded(col), dwp, M=Cout)
             dw = dwp.reshape(Cout, 3, Cc).permute(0, 2, 1).reshape(Cout, Cc, 3, 1, 1).contiguous()
-        db = _colsum(dy)[0] if bias is not None and need_dw[1] else None
-        return da, [dw, db]
+        return da, [dw, bias_grad(bias, need_dw[1])]
     raise ValueError(kind)
 
 
@@ -554,7 +576,19 @@ class Fused(torch.autograd.Function):
         need_norm_params = norm is not None and (nig[4] or nig[5])
         need_da = need_x or need_norm_params
         need_dw = list(nig[6:6 + ctx.n_params])
-        da, dps = _contract_bwd(kind, dy, a16, params, geo, need_da, need_dw)
+        # ONE pass over dY: rounded to the backward operand type for the dgrad / wgrad GEMMs, and summed per row block
+        # for the bias gradient (one block) / the per-frame vector's gradient (one block per `rows_per_vec` rows)
+        want_db = has_bias and kind != "qkv" and need_dw[1]
+        want_vec = has_vec and nig[3]
+        dy16 = db_pre = d_vec = None
+        if (want_db or want_vec) and _FUSE_DY_SUMS and dy.shape[1] % 8 == 0:
+            rows = spec["rows_per_vec"] if want_vec else dy.shape[0]
+            dy16, sums = _cast16_colsum(dy, _dt(GRAD_DTYPE), rows)
+            if want_vec:
+                d_vec = sums
+            if want_db:
+                db_pre = sums.sum(0) if want_vec else sums[0]
+        da, dps = _contract_bwd(kind, dy, a16, params, geo, need_da, need_dw, dy16, db_pre)
         dgamma = dbeta = None
         if norm is None:
             dx = da
@@ -573,7 +607,8 @@ class Fused(torch.autograd.Function):
             x, g32, stats, b32 = saved
             dx, dgamma, dbeta = _gn_bwd(x, da.contiguous(), stats, g32, b32, norm[1], norm[3])
         d_res = dy if has_res and nig[2] else None
-        d_vec = _colsum(dy, spec["rows_per_vec"]) if has_vec and nig[3] else None
+        if want_vec and d_vec is None:
+            d_vec = _colsum(dy, spec["rows_per_vec"])
         return (None, dx if need_x else None, d_res, d_vec, dgamma, dbeta, *dps)
 
 

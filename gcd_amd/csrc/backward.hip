@@ -580,6 +580,56 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const T* __restrict__ x,
   }
 }
 
+// fp32 -> fp16 / bf16 AND the column sums of every block of `rows_per_block` rows in the same pass: the incoming
+// gradient of a Linear / convolution is rounded for the dgrad / wgrad GEMMs and summed for the bias (one block) or
+// the per-frame epilogue vector (one block per frame) — one read of dY instead of two.
+// grid (ceil(C/64), nblk * chunks), block 256 = 8 column groups (8 channels) x 32 row lanes.
+template <bool BF>
+__global__ __launch_bounds__(256) void cast_colsum_kernel(const float* __restrict__ x, int64_t ldx,
+                                                          unsigned short* __restrict__ y, int64_t ldy,
+                                                          int64_t rows_per_block, int chunks, int rows_per_chunk, int C,
+                                                          float* __restrict__ sums) {
+  __shared__ float red[32][65];
+  const int t = threadIdx.x, cg = t & 7, rl = t >> 3;
+  const int c = blockIdx.x * 64 + cg * 8;
+  const int blk = blockIdx.y / chunks, ch = blockIdx.y - blk * chunks;
+  const int64_t r_begin = (int64_t)ch * rows_per_chunk;
+  int64_t r_end = r_begin + rows_per_chunk;
+  if (r_end > rows_per_block) r_end = rows_per_block;
+  const int64_t base = (int64_t)blk * rows_per_block;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    for (int64_t r = r_begin + rl; r < r_end; r += 32) {
+      const float* src = x + (base + r) * ldx + c;
+      const f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
+      typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+      us8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[e] += a[e];
+        acc[e + 4] += b[e];
+        if (BF) {
+          o[e] = bf16_rne(a[e]);
+          o[e + 4] = bf16_rne(b[e]);
+        } else {
+          o[e] = __builtin_bit_cast(unsigned short, (f16)a[e]);
+          o[e + 4] = __builtin_bit_cast(unsigned short, (f16)b[e]);
+        }
+      }
+      *(us8*)(y + (base + r) * ldy + c) = o;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][cg * 8 + e] = acc[e];
+  __syncthreads();
+  if (t < 64 && blockIdx.x * 64 + t < C) {
+    float s0 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) s0 += red[r][t];
+    atomicAdd(sums + (int64_t)blk * C + blockIdx.x * 64 + t, s0);
+  }
+}
+
 // torch.optim.Adam (no amsgrad; L2 weight decay added to the gradient), one fused pass
 // (diffusion.py:412-431 instantiates the optimizer the config names — Adam, lr 2e-5 for GCD).
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -847,6 +897,33 @@ extern "C" int gcd_cast_f32_bf16(const float* x, int64_t ldx, void* y16, int64_t
   GCD_CHECK_ARG(x && y16 && M > 0 && C > 0 && C % 4 == 0 && ldy % 4 == 0, "gcd_cast_f32_bf16: bad args");
   hipLaunchKernelGGL(cast_bf16_kernel<float>, dim3(grid_for(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, x,
                      ldx, (unsigned short*)y16, ldy, M, C);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gcd_cast_colsum_f32(const float* x, int64_t ldx, void* y16, int64_t ldy, int64_t M, int C,
+                                   int64_t rows_per_block, float* sums_zeroed, int to_bf16, void* stream) {
+  GCD_CHECK_ARG(x && y16 && sums_zeroed && M > 0 && C > 0 && C % 8 == 0 && ldx % 4 == 0 && ldy % 8 == 0 &&
+                    (((uintptr_t)x | (uintptr_t)y16) & 15) == 0,
+                "gcd_cast_colsum_f32: bad args (C=%d must be a multiple of 8, 16-byte aligned rows)", C);
+  GCD_CHECK_ARG(rows_per_block > 0 && M % rows_per_block == 0, "gcd_cast_colsum_f32: M=%lld rows_per_block=%lld",
+                (long long)M, (long long)rows_per_block);
+  const int64_t nblk = M / rows_per_block;
+  const int colb = (C + 63) / 64;
+  // ~2048 workgroups over the launch, at least 32 rows per chunk
+  int64_t chunks = (2048 + nblk * colb - 1) / (nblk * colb);
+  if (chunks < 1) chunks = 1;
+  if (chunks > (rows_per_block + 31) / 32) chunks = (rows_per_block + 31) / 32;
+  const int rpc = (int)((rows_per_block + chunks - 1) / chunks);
+  chunks = (rows_per_block + rpc - 1) / rpc;
+  GCD_CHECK_ARG(nblk * chunks <= 65535, "gcd_cast_colsum_f32: too many row blocks (%lld)", (long long)(nblk * chunks));
+  const dim3 grid(colb, (unsigned)(nblk * chunks));
+  if (to_bf16)
+    hipLaunchKernelGGL(cast_colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, (unsigned short*)y16,
+                       ldy, rows_per_block, (int)chunks, rpc, C, sums_zeroed);
+  else
+    hipLaunchKernelGGL(cast_colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, (unsigned short*)y16,
+                       ldy, rows_per_block, (int)chunks, rpc, C, sums_zeroed);
   GCD_CHECK_LAUNCH();
   return 0;
 }

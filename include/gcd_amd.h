@@ -340,6 +340,11 @@ int gcd_attn_temporal_bwd(const void* qkv16, int64_t ld, const float* dO, int64_
 /* y = bfloat16(x) (round to nearest even), for operand_bf16 GEMMs; x fp32 or (the _f16 form) fp16.      */
 int gcd_cast_f32_bf16(const float* x, int64_t ldx, void* y16, int64_t ldy, int64_t M, int C, void* stream);
 int gcd_cast_f16_bf16(const void* x16, int64_t ldx, void* y16, int64_t ldy, int64_t M, int C, void* stream);
+/* y16 = fp16 (or bfloat16 when to_bf16) of x AND sums[b][c] += sum of x over rows b*rows_per_block .. (sums zeroed by the
+ * caller, [M / rows_per_block, C]): the incoming gradient of a Linear / convolution rounded for its GEMMs and summed
+ * for its bias / per-frame-vector gradient in ONE pass over it.                                                      */
+int gcd_cast_colsum_f32(const float* x, int64_t ldx, void* y16, int64_t ldy, int64_t M, int C, int64_t rows_per_block,
+                        float* sums_zeroed, int to_bf16, void* stream);
 int gcd_cast_scale_f32_f16(const float* x, int64_t ldx, void* y16, int64_t ldy, int64_t M, int C,
                            float scale, void* stream);
 /* torch.optim.Adam step (no amsgrad; weight_decay added to the gradient), in place; grad_scale is
