@@ -268,7 +268,17 @@ def _pack_lin(dt):
 
 
 def _pack_lin_t(dt):
-    return lambda w: w.detach().reshape(w.shape[0], -1).t().to(dt).contiguous()   # [K, N], one rounding from fp32
+    """[K, N] = W^T in the operand type: ONE rounding from the fp32 parameter (a contiguous cast), then the 16-byte-vector
+    transpose kernel (torch's strided copy of `w.t().to(dt)` runs at a fraction of that; every Linear weight is repacked
+    after every optimizer step)."""
+    def pack(w):
+        w16 = w.detach().reshape(w.shape[0], -1).to(dt)
+        out = torch.empty(w16.shape[1], w16.shape[0], dtype=dt, device=w.device)
+        if w16.is_cuda:
+            ops.transpose_f16(w16.contiguous(), out)
+            return out
+        return w16.t().contiguous()
+    return pack
 
 
 def _pack_c3(dt, cin_p, cout_p):

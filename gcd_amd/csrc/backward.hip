@@ -189,10 +189,16 @@ __global__ __launch_bounds__(256) void rowblock_sum_kernel(const float* __restri
 //   n = rows_per_inst * C / 32                                                        -> kernel 2
 //   dgamma_c = sum_inst B_c,  dbeta_c = sum_inst A_c                                  (host, tiny)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void gn_bwd_reduce_kernel(
+// Round 3: per-channel constants live in LDS tables built once per workgroup (the first version re-derived group
+// index, statistics and affine per ELEMENT and ran its reduction on 168 workgroups with fp64 chains and 8 fp64 atomics
+// per thread: 0.6 TB/s); the reduction accumulates in fp32 per thread (<= 64 rows), combines the row lanes of a
+// workgroup in LDS and issues one fp64 atomic per (channel, workgroup).
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy, int C,
     int64_t rows_per_inst, int rows_per_chunk, int txw, int kpass, const float* __restrict__ stats,
     const float* __restrict__ gamma, const float* __restrict__ beta, int silu, double* __restrict__ AB) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* red = (float*)smem_raw;   // [rpp][txw * 8]
   const int t = threadIdx.x;
   const int cg = C / 32;
   const int inst = blockIdx.y, chunk = blockIdx.x;
@@ -200,8 +206,9 @@ __global__ __launch_bounds__(512) void gn_bwd_reduce_kernel(
   int64_t r1 = r0 + rows_per_chunk;
   if (r1 > rows_per_inst) r1 = rows_per_inst;
   const int64_t base = (int64_t)inst * rows_per_inst;
-  const int tx = t % txw, ty = t / txw;
   const int rpp = blockDim.x / txw;
+  const int tx = t % txw, ty = t / txw;
+  const bool on = ty < rpp;
   for (int kp = 0; kp < kpass; ++kp) {
     const int c = (tx + kp * txw) * 4;
     float mu[4], rs[4], ga[4], be[4];
@@ -213,25 +220,43 @@ __global__ __launch_bounds__(512) void gn_bwd_reduce_kernel(
       ga[e] = gamma[c + e];
       be[e] = beta[c + e];
     }
-    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
-    for (int64_t r = r0 + ty; r < r1; r += rpp) {
-      const f32x4 xv = *(const f32x4*)(x + (base + r) * ldx + c);
-      const f32x4 dv = *(const f32x4*)(dy + (base + r) * lddy + c);
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (on) {
+      for (int64_t r = r0 + ty; r < r1; r += rpp) {
+        const f32x4 xv = *(const f32x4*)(x + (base + r) * ldx + c);
+        const f32x4 dv = *(const f32x4*)(dy + (base + r) * lddy + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (xv[e] - mu[e]) * rs[e];
+          float dz = dv[e];
+          if (silu) dz *= dsilu_f(fmaf(ga[e], xh, be[e]));
+          a[e] += dz;
+          b[e] = fmaf(dz, xh, b[e]);
+        }
+      }
+      float* dst = red + ((int64_t)ty * txw + tx) * 8;
+      *(f32x4*)dst = f32x4{a[0], a[1], a[2], a[3]};
+      *(f32x4*)(dst + 4) = f32x4{b[0], b[1], b[2], b[3]};
+    }
+    __syncthreads();
+    if (on && ty == 0) {
+      double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+      for (int y = 0; y < rpp; ++y) {
+        const float* src = red + ((int64_t)y * txw + tx) * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sa[e] += (double)src[e];
+          sb[e] += (double)src[4 + e];
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float xh = (xv[e] - mu[e]) * rs[e];
-        float dz = dv[e];
-        if (silu) dz *= dsilu_f(fmaf(ga[e], xh, be[e]));
-        a[e] += (double)dz;
-        b[e] += (double)(dz * xh);
+        double* dst = AB + ((int64_t)inst * C + c + e) * 2;
+        atomicAdd(dst, sa[e]);
+        atomicAdd(dst + 1, sb[e]);
       }
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      double* dst = AB + ((int64_t)inst * C + c + e) * 2;
-      atomicAdd(dst, a[e]);
-      atomicAdd(dst + 1, b[e]);
-    }
+    __syncthreads();
   }
 }
 
@@ -240,6 +265,14 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     int64_t rows_per_inst, int rows_per_chunk, const float* __restrict__ stats,
     const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
     const double* __restrict__ AB, float* __restrict__ dx, int64_t lddx) {
+  // per-channel tables: mean, rstd, gamma, beta, s1 (group), s2 (group)
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* tmu = (float*)smem_raw;
+  float* trs = tmu + C;
+  float* tga = trs + C;
+  float* tbe = tga + C;
+  float* ts1 = tbe + C;
+  float* ts2 = ts1 + C;
   __shared__ float s1[32], s2[32];
   const int inst = blockIdx.y, t = threadIdx.x;
   const int cg = C / 32;
@@ -254,6 +287,16 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     s2[t] = (float)(b / n);
   }
   __syncthreads();
+  for (int c = t; c < C; c += 256) {
+    const int g = c / cg;
+    tmu[c] = stats[inst * 64 + 2 * g];
+    trs[c] = stats[inst * 64 + 2 * g + 1];
+    tga[c] = gamma[c];
+    tbe[c] = beta[c];
+    ts1[c] = s1[g];
+    ts2[c] = s2[g];
+  }
+  __syncthreads();
   const int cv4 = C >> 2;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk;
   int64_t nrows = rows_per_inst - r0;
@@ -265,16 +308,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     const int c = (int)(idx - r * cv4) * 4;
     const f32x4 xv = *(const f32x4*)(x + (base + r) * ldx + c);
     const f32x4 dv = *(const f32x4*)(dy + (base + r) * lddy + c);
+    const f32x4 mu = *(const f32x4*)(tmu + c), rs = *(const f32x4*)(trs + c), ga = *(const f32x4*)(tga + c);
+    const f32x4 be = *(const f32x4*)(tbe + c), g1 = *(const f32x4*)(ts1 + c), g2 = *(const f32x4*)(ts2 + c);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int g = (c + e) / cg;
-      const float mu = stats[inst * 64 + 2 * g], rs = stats[inst * 64 + 2 * g + 1];
-      const float xh = (xv[e] - mu) * rs;
-      const float ga = gamma[c + e];
+      const float xh = (xv[e] - mu[e]) * rs[e];
       float dz = dv[e];
-      if (silu) dz *= dsilu_f(fmaf(ga, xh, beta[c + e]));
-      o[e] = rs * (ga * dz - s1[g] - xh * s2[g]);
+      if (silu) dz *= dsilu_f(fmaf(ga[e], xh, be[e]));
+      o[e] = rs[e] * (ga[e] * dz - g1[e] - xh * g2[e]);
     }
     *(f32x4*)(dx + (base + r) * lddx + c) = o;
   }
@@ -797,20 +839,26 @@ extern "C" int gcd_groupnorm_bwd(const float* x, int64_t ldx, const float* dy, i
   hipStream_t s = (hipStream_t)stream;
   const int cv4 = C / 4;
   int kpass = 1;
-  while (cv4 % kpass != 0 || cv4 / kpass > 512) ++kpass;
+  while (cv4 % kpass != 0 || cv4 / kpass > 256) ++kpass;
   const int txw = cv4 / kpass;
-  int rpp = 320 / txw;
-  if (rpp < 1) rpp = 1;
-  int nchunks = (int)((rows_per_inst + 255) / 256);
-  if (nchunks > 128) nchunks = 128;
+  const int rpp = 256 / txw;
+  // ~1500 workgroups over the launch, at least 4 rows per row lane and chunk
+  int64_t want = (1536 + ninst - 1) / ninst;
+  int64_t nchunks = (rows_per_inst + 4 * rpp - 1) / (4 * rpp);
+  if (nchunks > want) nchunks = want;
+  if (nchunks < 1) nchunks = 1;
   const int rpc = (int)((rows_per_inst + nchunks - 1) / nchunks);
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nchunks, ninst), dim3(txw * rpp), 0, s, x, ldx, dy, lddy, C,
-                     rows_per_inst, rpc, txw, kpass, stats, gamma, beta, silu, AB_zeroed);
+  nchunks = (rows_per_inst + rpc - 1) / rpc;
+  GCD_CHECK_ARG(ninst <= 65535 && C * 24 <= 160 * 1024 - 512, "gcd_groupnorm_bwd: %d instances / C=%d too large", ninst, C);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3((unsigned)nchunks, ninst), dim3(256), rpp * txw * 8 * sizeof(float), s, x,
+                     ldx, dy, lddy, C, rows_per_inst, rpc, txw, kpass, stats, gamma, beta, silu, AB_zeroed);
   GCD_CHECK_LAUNCH();
   int achunks = (int)((rows_per_inst + 63) / 64);
   if (achunks > 1024) achunks = 1024;
   const int arpc = (int)((rows_per_inst + achunks - 1) / achunks);
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(achunks, ninst), dim3(256), 0, s, x, ldx, dy, lddy, C,
+  static GcdPerDeviceOnce attr_once;
+  if (C * 24 > 48 * 1024) GCD_CHECK_HIP(attr_once.opt_in((const void*)gn_bwd_apply_kernel, 160 * 1024 - 512));
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(achunks, ninst), dim3(256), C * 24, s, x, ldx, dy, lddy, C,
                      rows_per_inst, arpc, stats, gamma, beta, silu, AB_zeroed, dx, lddx);
   GCD_CHECK_LAUNCH();
   return 0;

@@ -22,14 +22,14 @@ def main():
     print(f"# source: {path}")
     print(f"# total GPU kernel time {tot:.3f} ms over {sum(r[1] for r in rows)} dispatches"
           + (f"; {steps:g} sampler steps in the trace -> {tot / steps:.3f} ms/step" if steps else ""))
-    hdr = f"{'kernel':100s} {'calls':>7s} {'total_ms':>10s} {'pct':>6s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>10s}"
+    hdr = f"{'kernel':150s} {'calls':>7s} {'total_ms':>10s} {'pct':>6s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>10s}"
     if steps:
         hdr += f" {'ms/step':>9s}"
     print(hdr)
     for name, n, t, avg, mn, mx in rows:
         if t / tot < 0.0005:
             continue
-        line = f"{name[:100]:100s} {n:7d} {t:10.3f} {100 * t / tot:6.2f} {avg:10.1f} {mn:9.1f} {mx:10.1f}"
+        line = f"{name[:150]:150s} {n:7d} {t:10.3f} {100 * t / tot:6.2f} {avg:10.1f} {mn:9.1f} {mx:10.1f}"
         if steps:
             line += f" {t / steps:9.3f}"
         print(line)
