@@ -620,8 +620,11 @@ def test_activation_checkpointing_matches(gpu):
         torch.cuda.synchronize()
         grads.append({n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None})
     assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 1000
-    for n in grads[0]:      # (bias / norm-parameter gradients are sums of atomics: equal up to summation order)
-        assert rel_l2(grads[1][n], grads[0][n]) < 1e-5, n
+    for n in grads[0]:
+        # weight gradients come out of GEMMs with a fixed summation order: equal to rounding; bias / norm-parameter
+        # / blend-logit gradients are fp32 sums of atomics whose ORDER differs between two runs
+        tol = 1e-5 if grads[0][n].dim() > 1 else 3e-4
+        assert rel_l2(grads[1][n], grads[0][n]) < tol, n
     print(f"activations held after forward: {held[0] / 2**20:.0f} MiB plain, {held[1] / 2**20:.0f} MiB checkpointed")
     assert held[1] < 0.5 * held[0]
 
