@@ -34,6 +34,7 @@ for dt in fp16 bf16; do python tools/train_step_bench.py --steps 3 --dtype $dt >
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/trace_train -o t -- python $ROOT/tools/train_step_bench.py --steps 2 \
     > /dev/null 2>&1)
 python tools/rocpd_stats.py $(find $OUT/trace_train -name "*_results.db" | head -1) > $OUT/train_kernel_stats.txt
-find $OUT -name "*.db" -delete
-find $OUT -name "*counter_collection.csv" -size +20M -delete
+# keep the summaries only: gpurun merges at most 64 MiB back
+rm -rf $OUT/trace $OUT/trace_train $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_TCC_HIT_sum $OUT/pmc_sq $OUT/pmc_sq2
+du -sh $ROOT/gpurun_out
 ls -la $OUT
