@@ -67,3 +67,84 @@ def _worker(rank, world, store, num_clips, q):
 @pytest.mark.parametrize("num_clips", [2, 3])
 def test_two_ranks_one_gpu_fused_loop_equals_single_process(gpu, num_clips):
     assert gloo_util.run_world(_worker, 2, num_clips, timeout=900) == {0: True, 1: True}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# cfg4 in miniature: data-parallel fine-tune step, two ranks on one GPU over gloo — each rank runs forward + backward
+# of the TINY VideoUNet on ITS batch on the HIP training path, gradients are exchanged by GradBucketer (all-reduce
+# launched from gradient hooks while the backward pass is still running), AdamHIP steps; the averaged gradients equal
+# the mean of the two per-batch gradients computed in one process, and both ranks end with identical weights.
+# ---------------------------------------------------------------------------------------------------------------
+def _train_setup(dev, seed):
+    from gcd_amd import training as TR
+    from gcd_amd.video_model import VideoUNet
+    from oracle import svd_unet_ref as O, weights
+    cfg = O.TINY
+    with torch.device("meta"):
+        net = VideoUNet(**cfg.as_reference_kwargs())
+    sd = weights.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 6)
+    net = net.to_empty(device=dev)
+    net.load_state_dict(sd)
+    net.train()
+    T, H, W = 4, 16, 16
+    g = torch.Generator().manual_seed(seed)
+    batch = dict(
+        x0=torch.randn(T, 4, H, W, generator=g).to(dev), noise=torch.randn(T, 4, H, W, generator=g).to(dev),
+        sig=torch.full((T,), float(torch.randn(1, generator=g).mul(1.6).add(1.0).exp())).to(dev),
+        cond={"crossattn": torch.randn(T, 1, cfg.context_dim, generator=g).to(dev),
+              "concat": (torch.randn(T, 4, H, W, generator=g) * 0.8).to(dev),
+              "vector": torch.randn(T, cfg.adm_in_channels + cfg.aux_emb_dim, generator=g).clamp(-1, 1).to(dev)})
+    den = TR.TrainDenoiser({"target": "gcd_amd.denoiser_scaling.VScalingWithEDMcNoise"})
+
+    def loss_of(b):
+        noised = b["x0"] + b["noise"] * b["sig"][:, None, None, None]
+        out = den(net, noised, b["sig"], b["cond"], num_video_frames=T, image_only_indicator=torch.zeros(1, T, device=dev))
+        return ((out - b["x0"]) ** 2).mean()
+    return net, batch, loss_of
+
+
+def _ddp_worker(rank, world, store, q):
+    import torch.distributed as dist
+    from gcd_amd import training as TR
+    gloo_util.init(rank, world, store)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        net, mine, loss_of = _train_setup(dev, 500 + rank)
+        bucketer = TR.GradBucketer(net.parameters(), dist, bucket_bytes=1 << 20)
+        (loss_of(mine) * 256.0).backward()
+        nb = bucketer.finish()
+        ok = nb >= 3 and bucketer.launched_during_backward >= 1
+        got = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+        if rank == 0:       # the same two batches in ONE process: mean of the two gradients
+            ref = {}
+            for r in range(world):
+                _, other, _ = _train_setup(dev, 500 + r)
+                for p in net.parameters():
+                    p.grad = None
+                (loss_of(other) * 256.0).backward()
+                for n, p in net.named_parameters():
+                    if p.grad is not None:
+                        ref[n] = ref.get(n, 0) + p.grad / world
+            num = sum(float((got[n].double() - ref[n].double()).pow(2).sum()) for n in ref)
+            den_ = sum(float(ref[n].double().pow(2).sum()) for n in ref)
+            err = (num / den_) ** 0.5
+            print(f"data-parallel gradients vs single-process mean: global rel-L2 {err:.2e}")
+            ok = ok and err < 1e-3 and set(ref) <= set(got)
+            for n, p in net.named_parameters():
+                p.grad = got.get(n)
+        opt = TR.AdamHIP(net.parameters(), lr=1e-4)
+        opt.step(grad_scale=1.0 / 256.0)
+        torch.cuda.synchronize()
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu()
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        ok = ok and all(torch.equal(gathered[0], t) for t in gathered[1:])
+        bucketer.close()
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_finetune_step_two_ranks_one_gpu(gpu):
+    assert gloo_util.run_world(_ddp_worker, 2, timeout=900) == {0: True, 1: True}
