@@ -4,8 +4,9 @@
 (`<dst_dp>/0000.png ...` via `matplotlib.pyplot.imsave`, `<dst_fp>.mp4` via `imageio.mimwrite(format='ffmpeg')`),
 the same float -> uint8 conversion (`(x * 255).astype(uint8)`: truncation, not rounding) and the same crop to
 a multiple of the codec's macro block AFTER the frames were saved.  Like the reference it does not raise when the
-video cannot be written (there: 10 attempts, each failure printed); here a missing `imageio` / ffmpeg is one such
-failure, reported once.  CPU / numpy work, not on the HIP path.
+video cannot be written (there: 10 attempts, each failure printed).  Without `imageio` / ffmpeg the `.mp4` is still
+written — same frames, same fps — as Motion-JPEG in an MP4 container (`gcd_amd/mp4_mjpeg.py`).  CPU / numpy work,
+not on the HIP path.
 """
 from __future__ import annotations
 
@@ -69,8 +70,17 @@ def write_video_and_frames(images, dst_dp: Optional[str] = None, dst_fp: Optiona
         frames = list(crop_to_multiple(images, crop_multiple))
         try:
             import imageio
-        except ImportError as e:     # one "attempt" that cannot succeed: say so once, as the reference prints
-            print(f"Error saving video: {e} (imageio with the ffmpeg plugin writes the .mp4)")
+        except ImportError as e:
+            # No imageio / ffmpeg (the reference's H.264 writer): still produce `<dst_fp>.mp4` — the same frames at
+            # the same fps as Motion-JPEG in an MP4 container (gcd_amd/mp4_mjpeg.py, PIL for the JPEGs).
+            print(f"imageio is not available ({e}): writing Motion-JPEG video to: {dst_fp}.mp4")
+            try:
+                from .mp4_mjpeg import write_mp4_mjpeg
+                info = write_mp4_mjpeg(dst_fp + ".mp4", frames, fps=float(fps), quality=quality)
+                written["video"] = dst_fp + ".mp4"
+                written["video_codec"] = info["codec"]
+            except Exception as e2:   # noqa: BLE001 — like the reference, a failed video never raises
+                print(f"Error saving video: {e2}")
             return written
         if hasattr(os, "sched_setaffinity"):   # eval_utils.py:546-549: ffmpeg should see every core
             try:
