@@ -1,13 +1,14 @@
 """ORACLE (test infrastructure, NOT product code): brute-force restatement of the image metrics GCD's
 evaluation uses (scripts/test.py:386-420 -> skimage.metrics 0.22.0; scripts/eval_utils.py:571-666).
 
-PARITY PIN: scikit-image is a third-party dependency of the reference that is absent from this
-image (requirements_versions.txt:40 pins 0.22.0) and the reference ships no golden values for its
-metrics, so this oracle is pinned to the published algorithm only: explicit window loops written
-from Wang et al. 2004 / the skimage documentation (7x7 uniform window, 'reflect' boundary as
-scipy.ndimage.uniform_filter's default, sample covariance, crop by the window radius) plus the
-closed-form known answers in tests/test_metrics.py.  Parity for this row is therefore "unpinned by
-reference outputs" and says so.
+PARITY PIN (round 3): the SSIM arithmetic is pinned to the REFERENCE'S OWN CODE — scripts/eval_utils.py:571-666
+(`masked_ssim`: skimage 0.22.0's structural_similarity as adapted by the reference authors) executed unmodified by
+oracle/make_golden_metrics.py (scikit-image, absent from this image, only contributes four one-line helpers, stubbed
+from their documented behaviour) -> tests/golden/metrics_kat.pt; tests/test_metrics.py holds gcd_amd.metrics to it
+at 1e-12.  This file remains the independent brute-force restatement (explicit window loops from Wang et al. 2004:
+7x7 uniform window, 'reflect' boundary as scipy.ndimage.uniform_filter's default, sample covariance, crop by the
+window radius) that the same tests also compare against.  Unpinned by reference outputs: only skimage's own entry
+points (`peak_signal_noise_ratio`, argument handling of `structural_similarity`), not the arithmetic.
 """
 from __future__ import annotations
 
