@@ -30,6 +30,9 @@ OUT = ROOT / "tests" / "golden"
 SALT, SEED = 4, 141
 B, T, H, W = 2, 14, 32, 48
 STEP = 0                 # global_step 0: plain per-frame mean (the focal top-k schedule starts at 1.0)
+# `python -m oracle.make_golden_cfg4 focal`: global_step 2500 instead — the annealed top-fraction ("focal") loss half-way
+# through its schedule (keep the 55 % largest per-pixel losses of every frame, 0.9 top + 0.1 mean; loss.py:236-256) ->
+# train_kubric_32x48_focal.pt (norms + 32 samples per gradient)
 
 
 def inputs():
@@ -48,6 +51,10 @@ def inputs():
 
 
 def main():
+    focal = "focal" in sys.argv[1:]
+    step = 2500 if focal else STEP
+    nsamp = 32 if focal else 128
+    fname = "train_kubric_32x48_focal.pt" if focal else "train_kubric_32x48.pt"
     torch.manual_seed(0)
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", str(os.cpu_count()))))
     cfg = O.KUBRIC
@@ -71,7 +78,7 @@ def main():
     out = den(model, noised, sig, cond, num_video_frames=T, image_only_indicator=torch.zeros(B, T))
     out = out.contiguous()      # the CPU convolution returns channels_last strides; get_loss uses .view (loss.py:244)
     w = loss_fn.loss_weighting(sig)[:, None, None, None]
-    loss = loss_fn.get_loss(out, x0, w, {"global_step": STEP}).mean()
+    loss = loss_fn.get_loss(out, x0, w, {"global_step": step}).mean()
     t1 = time.time()
     print(f"forward {t1 - t0:.0f} s, loss {float(loss):.6f}", flush=True)
     loss.backward()
@@ -82,14 +89,14 @@ def main():
             dead.append(name)
             continue
         norms[name] = float(p.grad.double().norm())
-        samples[name] = sample(p.grad, 128)
-    torch.save({"config": "KUBRIC", "salt": SALT, "seed": SEED, "B": B, "T": T, "H": H, "W": W, "step": STEP,
+        samples[name] = sample(p.grad, nsamp)
+    torch.save({"config": "KUBRIC", "salt": SALT, "seed": SEED, "B": B, "T": T, "H": H, "W": W, "step": step,
                 "loss": float(loss), "out_samples": sample(out.detach(), 65536),
                 "out_norm": float(out.detach().double().norm()),
                 "grad_norms": norms, "grad_samples": samples, "dead": dead,
                 "reference_cpu_seconds": time.time() - t0,
-                "reference_cpu_threads": torch.get_num_threads()}, OUT / "train_kubric_32x48.pt")
-    print(f"{len(norms)} gradients, {len(dead)} exactly-zero parameters; wrote train_kubric_32x48.pt", flush=True)
+                "reference_cpu_threads": torch.get_num_threads()}, OUT / fname)
+    print(f"{len(norms)} gradients, {len(dead)} exactly-zero parameters; wrote {fname}", flush=True)
 
 
 if __name__ == "__main__":

@@ -505,17 +505,21 @@ def test_unet_training_step_vs_oracle(gpu, step):
     assert moved > 0
 
 
-@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
-def test_training_step_full_width_cfg4_vs_reference_golden(gpu, dtype):
+@pytest.mark.parametrize("dtype,fixture", [("fp16", "train_kubric_32x48.pt"), ("bf16", "train_kubric_32x48.pt"),
+                                           ("fp16", "train_kubric_32x48_focal.pt")])
+def test_training_step_full_width_cfg4_vs_reference_golden(gpu, dtype, fixture):
     """BASELINE.json cfg4 at its own shape: ONE fine-tune step of the full-width 1.53 B-parameter Kubric VideoUNet on
     2 clips x 14 frames of 32 x 48 latents (N = 28, activation checkpointing as in every GCD config) against the
     UNMODIFIED reference classes' fp32 torch.autograd run on the CPU (oracle/make_golden_cfg4.py): loss, denoiser
     output, and for each of the ~1400 parameter gradients its norm and 128 strided samples.  Run with fp16 GEMM
-    operands (the inference engine's arithmetic) and with bf16 (what cfg4 names); the tolerance met is printed."""
+    operands (the inference engine's arithmetic) and with bf16 (what cfg4 names); the tolerance met is printed.
+    The `_focal` fixture is the same step at global_step 2500: the annealed top-fraction loss keeps the 55 % largest
+    per-pixel losses of every frame — a discrete choice that a 1e-3 difference of the output flips for the pixels at the
+    threshold, so its gradients differ by more than operand rounding (bars x3)."""
     from pathlib import Path
-    gold = Path(__file__).resolve().parent / "golden" / "train_kubric_32x48.pt"
+    gold = Path(__file__).resolve().parent / "golden" / fixture
     if not gold.exists():
-        pytest.skip("tests/golden/train_kubric_32x48.pt has not been generated (python -m oracle.make_golden_cfg4)")
+        pytest.skip(f"tests/golden/{fixture} has not been generated (python -m oracle.make_golden_cfg4 [focal])")
     from gcd_amd import autograd_ops as A
     from gcd_amd import training as TR
     from gcd_amd.video_model import VideoUNet
@@ -553,8 +557,10 @@ def test_training_step_full_width_cfg4_vs_reference_golden(gpu, dtype):
         A.set_train_dtype("fp16")
         A.PACK.clear()
     tol_out, tol_g = (2e-3, 5e-3) if dtype == "fp16" else (1.5e-2, 3e-2)
+    if G["step"] > 0:
+        tol_g *= 3.0
     e_out = rel_l2(sample(out.detach().cpu(), 65536), G["out_samples"])
-    print(f"[{dtype}] loss {float(loss):.6f} vs reference {G['loss']:.6f}; denoiser output rel-L2 {e_out:.2e}")
+    print(f"[{dtype}, step {G['step']}] loss {float(loss):.6f} vs reference {G['loss']:.6f}; denoiser output rel-L2 {e_out:.2e}")
     assert abs(float(loss) / G["loss"] - 1.0) < (2e-3 if dtype == "fp16" else 1e-2)
     assert e_out < tol_out
     num = den_ = 0.0
@@ -571,12 +577,12 @@ def test_training_step_full_width_cfg4_vs_reference_golden(gpu, dtype):
             continue
         ref_s = G["grad_samples"][name].double()
         got = prm.grad.detach().float().cpu() / loss_scale
-        got_s = sample(got, 128).double()
+        got_s = sample(got, 32 if G["step"] > 0 else 128).double()      # the fixture's grid (make_golden_cfg4.py)
         num += float((got_s - ref_s).pow(2).sum())
         den_ += float(ref_s.pow(2).sum())
         seen += 1
         rn = abs(float(got.double().norm()) / G["grad_norms"][name] - 1.0)
-        if ref_s.numel() >= 64:
+        if got.numel() >= 64:
             e = float((got_s - ref_s).norm() / ref_s.norm().clamp_min(1e-30))
             if e > worst[1]:
                 worst = (name, e)
