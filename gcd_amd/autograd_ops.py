@@ -6,17 +6,22 @@ gradient is a hand-written gfx950 kernel through the C ABI.
 
 Conventions
   * graph edges are fp32 token-major tensors [rows, channels] (gradients stay in fp32 between
-    operators); MFMA operands are rounded to fp16 inside each operator, exactly as in the inference
-    engine, with fp32 accumulation;
-  * contractions of the backward pass reuse `gcd_gemm_f16`:  dX = dY @ W (weights transposed once per
-    parameter version), dW = dY^T @ X (both operands transposed by `gcd_transpose_f16`, the token axis
-    zero-padded to the GEMM's 32-deep K granule); convolutions go through im2col / col2im
-    (`gcd_im2col3x3_f16` ...), the S x S attention products through plain GEMMs per (frame, head);
-  * static loss scaling as in AMP: the caller multiplies the loss by `loss_scale` so that the fp16
-    casts of the gradients keep their small values; parameter gradients come out scaled and the
-    optimizer step (`gcd_adam_step(grad_scale=1/loss_scale)`) removes the factor.
-This path is written for correctness first (gradient parity with torch.autograd on the CPU oracle,
-tests/test_backward_gpu.py); it is unfused and is not the measured inference path.
+    operators); MFMA operands are rounded to fp16 (or bf16: `set_train_dtype`) inside each operator,
+    exactly as in the inference engine, with fp32 accumulation;
+  * `Fused` is ONE node for [LayerNorm | GroupNorm(+SiLU) | GEGLU ->] Linear / q|k|v / Conv3x3 / Conv (3,1,1)
+    [+ per-frame vector] [+ residual]: the prologue writes the 16-bit GEMM operand directly, the epilogue terms ride
+    in the GEMM as in the inference engine;
+  * backward contractions reuse `gcd_gemm_f16`: dX of a Linear = dY @ W (W^T packed once per parameter version), dX of
+    a stride-1 convolution = the forward implicit-GEMM convolution on dY with mirrored taps (no col2im), dW = dY^T @ X
+    with both operands transposed by the vector transpose kernel and the GEMM split up to 32 ways along the token
+    axis (im2col feeds the convolutions' dW); dY is rounded and summed (bias / per-frame-vector gradients) in one pass;
+  * the spatial attention backward is flash-style (gcd_attn_spatial_bwd, attn_bwd.hip): nothing S x S in memory;
+  * static loss scaling as in AMP: the caller multiplies the loss by `loss_scale` so that the 16-bit casts of the
+    gradients keep their small values; parameter gradients come out scaled and the optimizer step
+    (`gcd_adam_step_multi(grad_scale=1/loss_scale)`) removes the factor.
+Gradient parity: tests/test_backward_gpu.py — per operator vs fp32 torch, per block and for the whole network vs
+torch.autograd over the CPU oracle, and the full-width step at cfg4's shape vs the unmodified reference classes
+(7.0e-4).  DESIGN.md §11 has the measurements.
 """
 from __future__ import annotations
 
@@ -736,8 +741,8 @@ def geglu(h):
 
 # ------------------------------------------------------------------------------------------------
 # Self-attention over the H*W tokens of a frame (d = 64 per head); qkv = [q | k | v] rows of 3C.
-# forward: the flash kernel of the inference path; backward: recompute P per (frame, head) with plain
-# GEMMs, dV = P^T dO, dP = dO V^T, dS = P (dP - rowsum(P dP)) / 8, dQ = dS K, dK = dS^T Q.
+# forward: the flash kernel of the inference path; backward: the flash-style kernels of attn_bwd.hip
+# (dV = P^T dO, dP = dO V^T, dS = P (dP - rowsum(dO O)) / 8, dQ = dS K, dK = dS^T Q, P recomputed per tile).
 # ------------------------------------------------------------------------------------------------
 class SpatialAttention(torch.autograd.Function):
     @staticmethod
