@@ -121,7 +121,13 @@ REFERENCE_AT_SHAPE = dict(value=0.0054, unit="steps/s", cores=8, seconds_per_ste
                                      "step via oracle/ref_shim.py at 14x72x128 latents on the build "
                                      "container's 8 cores (the reference tree does not exist on the GPU "
                                      "box); re-measured while generating tests/golden/"
-                                     "unet_kubric_72x128.pt (forward only)")
+                                     "unet_kubric_72x128.pt (forward only)",
+                          full_loop=dict(
+                              what="the UNMODIFIED reference stack running cfg1's whole 25-step loop at 14x72x128 "
+                                   "(oracle/make_golden_loop72.py, the run that produced tests/golden/"
+                                   "loop_kubric_72x128.pt)",
+                              cores=6, seconds_per_step_median=268.5, seconds_per_step_min=208.2,
+                              seconds_per_step_max=461.7, steps_per_s=round(1.0 / 268.5, 5), loop_seconds=7036))
 
 
 def cpu_baseline_and_parity(net, sampler, fd, T, dev, seed, cond):
