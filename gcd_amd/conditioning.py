@@ -71,87 +71,87 @@ class GeneralConditioner(nn.Module):
 
     def __init__(self, emb_models):
         super().__init__()
-        import numpy as np
         from .util import instantiate_from_config
-        embedders = []
-        for n, embconfig in enumerate(emb_models):
-            embedder = instantiate_from_config(embconfig)
-            assert isinstance(embedder, AbstractEmbModel), \
-                f"embedder model {embedder.__class__.__name__} has to inherit from AbstractEmbModel"
-            embedder.is_trainable = embconfig.get("is_trainable", False)
-            embedder.ucg_rate = embconfig.get("ucg_rate", 0.0)
-            if not embedder.is_trainable:
-                embedder.train = _disabled_train.__get__(embedder)
-                for param in embedder.parameters():
-                    param.requires_grad = False
-                embedder.eval()
-            if "input_key" in embconfig:
-                embedder.input_key = embconfig["input_key"]
-            elif "input_keys" in embconfig:
-                embedder.input_key = None
-                embedder.input_keys = embconfig["input_keys"]
-            else:
-                raise KeyError(f"need either 'input_key' or 'input_keys' for embedder "
-                               f"{embedder.__class__.__name__}")
-            embedder.legacy_ucg_val = embconfig.get("legacy_ucg_value", None)
-            if embedder.legacy_ucg_val is not None:
-                embedder.ucg_prng = np.random.RandomState()
-            embedders.append(embedder)
-        self.embedders = nn.ModuleList(embedders)
+        built = []
+        for cfg in emb_models:
+            emb = instantiate_from_config(cfg)
+            if not isinstance(emb, AbstractEmbModel):
+                raise AssertionError(f"embedder model {type(emb).__name__} has to inherit from AbstractEmbModel")
+            self._configure(emb, cfg)
+            built.append(emb)
+        self.embedders = nn.ModuleList(built)
+
+    @staticmethod
+    def _configure(emb: AbstractEmbModel, cfg) -> None:
+        """The per-embedder switches of the YAML entry (encoders/modules.py:97-131)."""
+        emb.is_trainable = cfg.get("is_trainable", False)
+        emb.ucg_rate = cfg.get("ucg_rate", 0.0)
+        if not emb.is_trainable:                    # frozen: no gradients, pinned to eval mode
+            emb.requires_grad_(False)
+            emb.train = _disabled_train.__get__(emb)
+            emb.eval()
+        single, several = cfg.get("input_key"), cfg.get("input_keys")
+        if "input_key" in cfg:
+            emb.input_key = single
+        elif "input_keys" in cfg:
+            emb.input_key, emb.input_keys = None, several
+        else:
+            raise KeyError(f"need either 'input_key' or 'input_keys' for embedder {type(emb).__name__}")
+        emb.legacy_ucg_val = cfg.get("legacy_ucg_value", None)
+        if emb.legacy_ucg_val is not None:
+            import numpy as np
+            emb.ucg_prng = np.random.RandomState()
 
     def possibly_get_ucg_val(self, embedder, batch):
+        """Legacy classifier-free dropout: overwrite entries of the INPUT with `legacy_ucg_val` at rate `ucg_rate`."""
         assert embedder.legacy_ucg_val is not None
-        p, val = embedder.ucg_rate, embedder.legacy_ucg_val
-        for i in range(len(batch[embedder.input_key])):
-            if embedder.ucg_prng.choice(2, p=[1 - p, p]):
-                batch[embedder.input_key][i] = val
+        rate, entries = embedder.ucg_rate, batch[embedder.input_key]
+        for i in range(len(entries)):
+            if embedder.ucg_prng.choice(2, p=[1 - rate, rate]):
+                entries[i] = embedder.legacy_ucg_val
         return batch
 
+    def _embed(self, emb, batch):
+        """One embedder's outputs as a list (frozen embedders run under no_grad)."""
+        key = getattr(emb, "input_key", None)
+        with torch.set_grad_enabled(bool(emb.is_trainable) and torch.is_grad_enabled()):
+            if key is not None:
+                if emb.legacy_ucg_val is not None:
+                    batch = self.possibly_get_ucg_val(emb, batch)
+                out = emb(batch[key])
+            else:
+                out = emb(*(batch[k] for k in emb.input_keys))
+        if not isinstance(out, (torch.Tensor, list, tuple)):
+            raise AssertionError(f"encoder outputs must be tensors or a sequence, but got {type(out)}")
+        return list(out) if isinstance(out, (list, tuple)) else [out]
+
     def forward(self, batch, force_zero_embeddings=None):
-        from contextlib import nullcontext
-        output = dict()
-        if force_zero_embeddings is None:
-            force_zero_embeddings = []
-        for embedder in self.embedders:
-            ctx = nullcontext if embedder.is_trainable else torch.no_grad
-            with ctx():
-                if getattr(embedder, "input_key", None) is not None:
-                    if embedder.legacy_ucg_val is not None:
-                        batch = self.possibly_get_ucg_val(embedder, batch)
-                    emb_out = embedder(batch[embedder.input_key])
-                elif hasattr(embedder, "input_keys"):
-                    emb_out = embedder(*[batch[k] for k in embedder.input_keys])
-            assert isinstance(emb_out, (torch.Tensor, list, tuple)), \
-                f"encoder outputs must be tensors or a sequence, but got {type(emb_out)}"
-            if not isinstance(emb_out, (list, tuple)):
-                emb_out = [emb_out]
-            for emb in emb_out:
-                out_key = self.OUTPUT_DIM2KEYS[emb.dim()]
-                if embedder.ucg_rate > 0.0 and embedder.legacy_ucg_val is None:
-                    keep = torch.bernoulli((1.0 - embedder.ucg_rate)
-                                           * torch.ones(emb.shape[0], device=emb.device))
-                    emb = _expand_dims_like(keep, emb) * emb      # per row of the batch = per frame
-                if getattr(embedder, "input_key", None) is not None and \
-                        embedder.input_key in force_zero_embeddings:
-                    emb = torch.zeros_like(emb)
-                if out_key in output:
-                    output[out_key] = torch.cat((output[out_key], emb), self.KEY2CATDIM[out_key])
-                else:
-                    output[out_key] = emb
-        return output
+        zeroed = set(force_zero_embeddings or ())
+        parts = {}                                      # output key -> tensors in embedder order
+        for emb in self.embedders:
+            key = getattr(emb, "input_key", None)
+            for t in self._embed(emb, batch):
+                if emb.ucg_rate > 0.0 and emb.legacy_ucg_val is None:
+                    # drop whole rows of the batch (= frames) with probability ucg_rate
+                    keep = torch.bernoulli(torch.full((t.shape[0],), 1.0 - emb.ucg_rate, device=t.device))
+                    t = _expand_dims_like(keep, t) * t
+                if key is not None and key in zeroed:
+                    t = torch.zeros_like(t)
+                parts.setdefault(self.OUTPUT_DIM2KEYS[t.dim()], []).append(t)
+        return {k: (v[0] if len(v) == 1 else torch.cat(v, self.KEY2CATDIM[k])) for k, v in parts.items()}
 
     def get_unconditional_conditioning(self, batch_c, batch_uc=None, force_uc_zero_embeddings=None,
                                        force_cond_zero_embeddings=None):
-        if force_uc_zero_embeddings is None:
-            force_uc_zero_embeddings = []
-        ucg_rates = []
-        for embedder in self.embedders:
-            ucg_rates.append(embedder.ucg_rate)
-            embedder.ucg_rate = 0.0
-        c = self(batch_c, force_cond_zero_embeddings)
-        uc = self(batch_c if batch_uc is None else batch_uc, force_uc_zero_embeddings)
-        for embedder, rate in zip(self.embedders, ucg_rates):
-            embedder.ucg_rate = rate
+        """(c, uc) with the row dropout switched off for both passes (encoders/modules.py:190-208)."""
+        saved = [emb.ucg_rate for emb in self.embedders]
+        for emb in self.embedders:
+            emb.ucg_rate = 0.0
+        try:
+            c = self(batch_c, force_cond_zero_embeddings)
+            uc = self(batch_c if batch_uc is None else batch_uc, force_uc_zero_embeddings or [])
+        finally:
+            for emb, rate in zip(self.embedders, saved):
+                emb.ucg_rate = rate
         return c, uc
 
 
