@@ -15,6 +15,8 @@ cores, ≈16 GiB RSS), so every job checkpoints its state under /tmp and resumes
                                                 x_35 = n * sqrt(1 + sigma_35^2)  (the marginal of the EDM
                                                 forward process on unit-variance data)
                                                                                -> loop_pardom_72x128_tail.pt
+  python -m oracle.make_golden_loop72 cfg3      cfg3 in full: ParDom net, all 50 steps at 14 x 72 x 128 (~3 h)
+                                                                               -> loop_pardom_72x128.pt
 
 Fixtures hold 65 536 strided samples + the norm of x after the KEEP steps and the full final latents
 (2 MB, needed to decode frames for the PSNR check).  The sampling grid is make_golden_fullres.sample.
@@ -41,6 +43,7 @@ JOBS = {
     "cfg1":     ("KUBRIC", 2,   181, 72, 128, 25,   0,    (1, 5, 10, 15, 20, 25),           "loop_kubric_72x128.pt"),
     "cfg3mid":  ("PARDOM", 3,   193, 40, 64,  50,   0,    (1, 10, 20, 30, 40, 45, 50),      "loop_pardom_40x64.pt"),
     "cfg3tail": ("PARDOM", 3,   194, 72, 128, 50,   35,   (36, 38, 40, 42, 44, 46, 48, 50), "loop_pardom_72x128_tail.pt"),
+    "cfg3":     ("PARDOM", 3,   195, 72, 128, 50,   0,    (1, 10, 20, 30, 40, 45, 50),      "loop_pardom_72x128.pt"),
 }
 
 

@@ -476,6 +476,15 @@ def test_sampler_50_steps_40x64_pardom_cfg3_vs_reference_golden(gpu):
     assert max(errs.values()) < TOL_LOOP and e < TOL_LOOP, f"50-step ParDom loop at 40x64: rel-L2 {e:.3e}"
 
 
+def test_sampler_50_steps_72x128_pardom_cfg3_vs_reference_golden(gpu):
+    """BASELINE.json cfg3 IN FULL at the metric's own resolution: the ParDom network's whole 50-step EulerEDM + CFG loop
+    on a 14 x 72 x 128 latent clip against the unmodified reference stack (oracle/make_golden_loop72.py cfg3; ~3 h of
+    CPU time once)."""
+    errs, e, z, g = _loop_vs_reference_golden(gpu, "loop_pardom_72x128.pt")
+    print("cfg3 72x128 trajectory rel-L2:", {k: f"{v:.2e}" for k, v in errs.items()}, f"final {e:.3e}")
+    assert max(errs.values()) < TOL_LOOP and e < TOL_LOOP, f"50-step ParDom loop at 72x128: rel-L2 {e:.3e}"
+
+
 def test_sampler_last_15_of_50_steps_72x128_pardom_cfg3_vs_reference_golden(gpu):
     """cfg3 at 14 x 72 x 128: the last 15 of the 50 steps (sigma_35 = 1.17 ... 0), where the network term carries the
     result, from the fixture's seeded mid-trajectory state, against the reference stack."""
