@@ -17,6 +17,10 @@ cores, ≈16 GiB RSS), so every job checkpoints its state under /tmp and resumes
                                                                                -> loop_pardom_72x128_tail.pt
   python -m oracle.make_golden_loop72 cfg3      cfg3 in full: ParDom net, all 50 steps at 14 x 72 x 128 (~3 h)
                                                                                -> loop_pardom_72x128.pt
+  python -m oracle.make_golden_loop72 cfg1b2mid num_samples = 2 (scripts/test.py:326): TWO clips in one sampler call
+                                                (2 x 14 frames, 56 under CFG), Kubric net, the full 25-step loop at
+                                                40 x 64                        -> loop_kubric_b2_40x64.pt
+  python -m oracle.make_golden_loop72 cfg1b2    the same at 72 x 128 (~4-5 h)  -> loop_kubric_b2_72x128.pt
 
 Fixtures hold 65 536 strided samples + the norm of x after the KEEP steps and the full final latents
 (2 MB, needed to decode frames for the PSNR check).  The sampling grid is make_golden_fullres.sample.
@@ -44,7 +48,11 @@ JOBS = {
     "cfg3mid":  ("PARDOM", 3,   193, 40, 64,  50,   0,    (1, 10, 20, 30, 40, 45, 50),      "loop_pardom_40x64.pt"),
     "cfg3tail": ("PARDOM", 3,   194, 72, 128, 50,   35,   (36, 38, 40, 42, 44, 46, 48, 50), "loop_pardom_72x128_tail.pt"),
     "cfg3":     ("PARDOM", 3,   195, 72, 128, 50,   0,    (1, 10, 20, 30, 40, 45, 50),      "loop_pardom_72x128.pt"),
+    # num_samples = 2 (scripts/test.py:326): TWO clips in one sampler call, 56 frames under CFG
+    "cfg1b2mid": ("KUBRIC", 2,  201, 40, 64,  25,   0,    (1, 5, 10, 15, 20, 25),           "loop_kubric_b2_40x64.pt"),
+    "cfg1b2":   ("KUBRIC", 2,   202, 72, 128, 25,   0,    (1, 5, 10, 15, 20, 25),           "loop_kubric_b2_72x128.pt"),
 }
+CLIPS = {"cfg1b2mid": 2, "cfg1b2": 2}
 
 
 def main(job: str):
@@ -60,12 +68,13 @@ def main(job: str):
     net.load_state_dict(weights.synth_state_dict(shapes, salt))
     net.eval()
     T = 14
-    noise, c, uc = weights.synth_inputs(1, T, h, w, cfg.context_dim,
+    B = CLIPS.get(job, 1)
+    noise, c, uc = weights.synth_inputs(B, T, h, w, cfg.context_dim,
                                         cfg.adm_in_channels + cfg.aux_emb_dim, seed)
     sampler = EulerEDMSampler(num_steps=steps, device="cpu", **ref_shim.SAMPLER_CFG)
     den = Denoiser(ref_shim.DENOISER_CFG)
     model = OpenAIWrapper(net)
-    extra = {"num_video_frames": T, "image_only_indicator": torch.zeros(2, T)}
+    extra = {"num_video_frames": T, "image_only_indicator": torch.zeros(2 * B, T)}
 
     def denoiser(inp, sigma, cc):
         return den(model, inp, sigma, cc, **extra)
@@ -93,7 +102,7 @@ def main(job: str):
         torch.save({"x": x, "done": i + 1, "trace": trace, "secs": secs}, state)
         print(f"[{job}] step {i + 1}/{steps}: {secs[-1]:.0f} s, sigma {float(sigmas[i]):.4f} -> "
               f"{float(sigmas[i + 1]):.4f}, std {float(x.std()):.4f}", flush=True)
-    torch.save({"config": cfg_name, "salt": salt, "T": T, "h": h, "w": w, "steps": steps,
+    torch.save({"config": cfg_name, "salt": salt, "T": T, "clips": B, "h": h, "w": w, "steps": steps,
                 "first_step": first, "input_seed": seed, "sigmas": sigmas.clone(),
                 "trace": trace, "final": x.clone(), "final_norm": float(x.double().norm()),
                 "reference_cpu_seconds_per_step": secs,

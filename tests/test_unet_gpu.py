@@ -173,13 +173,13 @@ def _sampler(T, steps, device):
         device=device)
 
 
-def _stack(net, T, gpu):
+def _stack(net, T, gpu, clips=1):
     from gcd_amd.denoiser import Denoiser
     from gcd_amd.sampling import FusedDenoiser
     from gcd_amd.wrappers import OpenAIWrapper
     den = Denoiser({"target": "gcd_amd.denoiser_scaling.VScalingWithEDMcNoise"})
     model = OpenAIWrapper(net)
-    extra = {"num_video_frames": T, "image_only_indicator": torch.zeros(2, T, device=gpu)}
+    extra = {"num_video_frames": T, "image_only_indicator": torch.zeros(2 * clips, T, device=gpu)}
     return den, model, extra, FusedDenoiser(den, model, **extra)
 
 
@@ -410,9 +410,10 @@ def _loop_vs_reference_golden(gpu, fname):
     net, sd = _build(cfg, gpu, salt=g["salt"])
     del sd
     T, steps, h, w, first = g["T"], g["steps"], g["h"], g["w"], g["first_step"]
-    noise, c, uc = weights.synth_inputs(1, T, h, w, cfg.context_dim, cfg.adm_in_channels + cfg.aux_emb_dim,
+    clips = g.get("clips", 1)     # num_samples: several clips in ONE sampler call (scripts/test.py:326)
+    noise, c, uc = weights.synth_inputs(clips, T, h, w, cfg.context_dim, cfg.adm_in_channels + cfg.aux_emb_dim,
                                         g["input_seed"])
-    den, model, extra, fused = _stack(net, T, gpu)
+    den, model, extra, fused = _stack(net, T, gpu, clips)
     sampler = _sampler(T, steps, "cuda")
     loop = FusedEulerLoop(sampler, fused, noise.clone().to(gpu),
                           {k: v.to(gpu) for k, v in c.items()}, {k: v.to(gpu) for k, v in uc.items()})
@@ -447,11 +448,14 @@ def test_sampler_25_steps_72x128_cfg1_vs_reference_golden(gpu):
     print("cfg1 72x128 trajectory rel-L2:", {k: f"{v:.2e}" for k, v in errs.items()}, f"final {e:.3e}")
     assert max(errs.values()) < TOL_LOOP and e < TOL_LOOP, f"25-step loop at 72x128: rel-L2 {e:.3e}"
     # decoded frames at 576 x 1024 through the HIP first-stage decoder (full 128-channel VideoDecoder, procedural
-    # weights): what a 1e-3 difference of the latents is in pixels
+    # weights) against (a) the frames the UNMODIFIED reference VideoDecoder made from the reference loop's own final
+    # latents (oracle/make_golden_decoder72.py: the reference stack end to end, loop + decode) and (b) the HIP
+    # decoder on the reference's latents (what the latent error alone is in pixels)
     import math
     from gcd_amd.first_stage import decode_first_stage
     from gcd_amd.temporal_ae import VideoDecoder
     from oracle import vae_decoder_ref as D
+    from oracle.make_golden_fullres import sample
     with torch.device("meta"):
         dec = VideoDecoder(**D.KUBRIC.as_reference_kwargs())
     sdd = weights.synth_state_dict({k: tuple(v.shape) for k, v in dec.state_dict().items()}, salt=1)
@@ -459,14 +463,40 @@ def test_sampler_25_steps_72x128_cfg1_vs_reference_golden(gpu):
     dec.load_state_dict(sdd)
     dec.eval()
     frames = decode_first_stage(dec, z, 0.18215, en_and_decode_n_samples_a_time=14).cpu()
-    frames_ref = decode_first_stage(dec, g["final"].to(gpu), 0.18215, en_and_decode_n_samples_a_time=14).cpu()
     assert frames.shape == (14, 3, 576, 1024)
+    gd_path = GOLD / "decoder_kubric_72x128.pt"
+    if gd_path.exists():
+        gd = torch.load(gd_path)
+        got = sample(frames, gd["out_samples"].numel())
+        mse = float(((got.double() - gd["out_samples"].double()) ** 2).mean())
+        psnr_ref = 10.0 * math.log10(4.0 / max(mse, 1e-30))
+        print(f"576x1024 frames, HIP loop + HIP decoder vs REFERENCE loop + REFERENCE decoder: rel-L2 "
+              f"{rel_l2(got, gd['out_samples']):.3e}, PSNR {psnr_ref:.1f} dB on the [-1, 1] range")
+        assert psnr_ref >= 60.0
+    frames_ref = decode_first_stage(dec, g["final"].to(gpu), 0.18215, en_and_decode_n_samples_a_time=14).cpu()
     mse = float(((frames.double() - frames_ref.double()) ** 2).mean())
     psnr = 10.0 * math.log10(4.0 / max(mse, 1e-30))
-    print(f"decoded 576x1024 frames: rel-L2 {rel_l2(frames, frames_ref):.3e}, PSNR {psnr:.1f} dB on the [-1, 1] range")
-    assert psnr >= 55.0
+    print(f"576x1024 frames, latent error alone (HIP decoder on both): rel-L2 {rel_l2(frames, frames_ref):.3e}, "
+          f"PSNR {psnr:.1f} dB")
+    assert psnr >= 65.0
     del dec
     torch.cuda.empty_cache()
+
+
+def test_sampler_25_steps_two_clips_40x64_cfg1_vs_reference_golden(gpu):
+    """num_samples = 2 (scripts/test.py:326): TWO clips in one sampler call (28 frames, 56 under CFG), the full 25-step
+    loop of the full-width Kubric network at 40 x 64 latents against the UNMODIFIED reference plugin stack's own
+    trajectory (oracle/make_golden_loop72.py cfg1b2mid) under the 1e-3 loop contract."""
+    errs, e, z, g = _loop_vs_reference_golden(gpu, "loop_kubric_b2_40x64.pt")
+    print("cfg1 B=2 40x64 trajectory rel-L2:", {k: f"{v:.2e}" for k, v in errs.items()}, f"final {e:.3e}")
+    assert z.shape[0] == 28 and max(errs.values()) < TOL_LOOP and e < TOL_LOOP, f"B=2 25-step loop: rel-L2 {e:.3e}"
+
+
+def test_sampler_25_steps_two_clips_72x128_cfg1_vs_reference_golden(gpu):
+    """The same at the metric's own resolution (cfg1b2; skips until that ~4 h fixture has been generated)."""
+    errs, e, z, g = _loop_vs_reference_golden(gpu, "loop_kubric_b2_72x128.pt")
+    print("cfg1 B=2 72x128 trajectory rel-L2:", {k: f"{v:.2e}" for k, v in errs.items()}, f"final {e:.3e}")
+    assert z.shape[0] == 28 and max(errs.values()) < TOL_LOOP and e < TOL_LOOP, f"B=2 25-step loop: rel-L2 {e:.3e}"
 
 
 def test_sampler_50_steps_40x64_pardom_cfg3_vs_reference_golden(gpu):
@@ -496,7 +526,8 @@ def test_sampler_last_15_of_50_steps_72x128_pardom_cfg3_vs_reference_golden(gpu)
 def test_two_clips_batched_with_image_only_indicator(gpu, tiny):
     """num_samples / batched clips: B = 2 clips in one call (56 frames under CFG: per-clip time_stack
     GroupNorm, per-clip first-frame temporal context, > 32 rows through the small-M kernel), with a
-    non-zero image_only_indicator (4, 14) — UNet forward and the fused 5-step loop vs the oracle."""
+    non-zero image_only_indicator (4, 14) — UNet forward and the fused loop vs the oracle: 5 steps (short loop, relaxed
+    bar) and the full 25 steps under the 1e-3 contract."""
     net, sd = tiny
     T, h, w, B = 14, 8, 8, 2
     cfg = O.TINY
@@ -530,5 +561,13 @@ def test_two_clips_batched_with_image_only_indicator(gpu, tiny):
     got = sampler(fd, noise.clone().to(gpu), cond={k: v.to(gpu) for k, v in c.items()},
                   uc={k: v.to(gpu) for k, v in uc.items()})
     e = rel_l2(got, ref_loop)
-    print(f"B=2 fused loop rel-L2 {e:.3e}")
+    print(f"B=2 fused 5-step loop rel-L2 {e:.3e}")
     assert sampler.last_path == "fused" and got.shape[0] == B * T and e < 1.5 * TOL_LOOP
+    with torch.no_grad():
+        ref25 = O.sample_loop(sd, cfg, noise, c, uc, T, 25, ioi2=ioi)
+    sampler25 = _sampler(T, 25, "cuda")
+    got25 = sampler25(fd, noise.clone().to(gpu), cond={k: v.to(gpu) for k, v in c.items()},
+                      uc={k: v.to(gpu) for k, v in uc.items()})
+    e25 = rel_l2(got25, ref25)
+    print(f"B=2 fused 25-step loop rel-L2 {e25:.3e}")
+    assert sampler25.last_path == "fused" and e25 < TOL_LOOP, f"B=2 25-step loop: rel-L2 {e25:.3e}"
