@@ -32,6 +32,7 @@ from typing import Dict, Iterable, List, Optional
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import autograd_ops as A
 from . import ops
@@ -293,6 +294,15 @@ class EDMWeighting:
         return (sigma ** 2 + self.sigma_data ** 2) / (sigma * self.sigma_data) ** 2
 
 
+# ParallelDomain semantic-map palette of the classes the loss can up-weight (the dataset's colour coding, as listed at
+# loss.py:16-33; "Train" is left out there because of its size).
+PD_PERSON_RGB = {"Animal": (220, 20, 180), "Bicyclist": (64, 64, 64), "Motorcyclist": (128, 128, 128),
+                 "OtherRider": (192, 192, 192), "Pedestrian": (220, 20, 60)}
+PD_VEHICLE_RGB = {"Bus": (0, 60, 100), "Car": (0, 0, 142), "Caravan/RV": (0, 0, 90),
+                  "ConstructionVehicle": (32, 32, 32), "Bicycle": (119, 11, 32), "Motorcycle": (0, 0, 230),
+                  "OwnCar": (128, 230, 128), "Truck": (0, 0, 70), "WheeledSlow": (0, 64, 64)}
+
+
 class StandardDiffusionLoss(nn.Module):
     """Drop-in for sgm.modules.diffusionmodules.loss.StandardDiffusionLoss (loss.py:57-273): same
     constructor keywords, `forward(network, denoiser, conditioner, input, batch)` and `_forward(network,
@@ -340,25 +350,49 @@ class StandardDiffusionLoss(nn.Module):
         w = append_dims(self.loss_weighting(sigmas), input.ndim)
         return self.get_loss(out, input, w, batch)
 
+    def _pd_class_weight_map(self, gt_rgb: torch.Tensor, latent_hw) -> torch.Tensor:
+        """loss.py:196-230 (configs/train_pardom_semantic.yaml:145-146): per latent pixel, sum over the selected
+        ParallelDomain classes of (class weight - 1) x the fraction of the pixels of its 8 x 8 square whose
+        semantic-map colour matches the class (mean absolute channel difference < 0.02 on the [-1, 1] range).
+        Returns (BT, 1, Hl, Wl); the reference adds `loss_raw * mask * (weight - 1)` class by class, this is the
+        same sum with the class loop inside the map."""
+        classes = []
+        if self.pd_person_weight > 1.0:
+            classes += [(rgb, self.pd_person_weight) for rgb in PD_PERSON_RGB.values()]
+        if self.pd_vehicle_weight > 1.0:
+            classes += [(rgb, self.pd_vehicle_weight) for rgb in PD_VEHICLE_RGB.values()]
+        wmap = torch.zeros(gt_rgb.shape[0], 1, *latent_hw, dtype=torch.float32, device=gt_rgb.device)
+        for rgb, weight in classes:
+            colour = torch.tensor(rgb, dtype=torch.float32, device=gt_rgb.device) / 127.5 - 1.0
+            match = ((gt_rgb - colour[None, :, None, None]).abs().mean(dim=1, keepdim=True) < 0.02).float()
+            wmap += F.interpolate(match, tuple(latent_hw), mode="area") * (weight - 1.0)
+        return wmap
+
     def get_loss(self, model_output, target, w, batch):
-        """loss.py:163-273: L2 / L1, then the annealed top-fraction focal loss (keep the `cur_top`
-        largest per-pixel losses of every frame, 0.9 top + 0.1 mean), then the EDM weighting."""
-        if self.pd_person_weight > 1.0 or self.pd_vehicle_weight > 1.0:
-            raise NotImplementedError("ParallelDomain class re-weighting needs batch['jpg'] semantic colours")
+        """loss.py:163-273: L2 / L1; the ParallelDomain class re-weighting (half of it enters before the focal
+        selection, half after); the annealed top-fraction focal loss (keep the `cur_top` largest per-pixel losses of
+        every frame, 0.9 top + 0.1 mean); the EDM weighting."""
         diff = model_output - target
         BT = target.shape[0]
         loss_raw = diff ** 2 if self.loss_type == "l2" else diff.abs()
+        if self.pd_person_weight > 1.0 or self.pd_vehicle_weight > 1.0:
+            loss_bias = loss_raw * self._pd_class_weight_map(batch["jpg"].detach().to(loss_raw), target.shape[2:4])
+            bias_mean = loss_bias.reshape(BT, -1).mean(dim=1)
+            loss_all = loss_raw + loss_bias * 0.5
+        else:
+            bias_mean = 0.0
+            loss_all = loss_raw
         cur_step = batch["global_step"]
         progress = min(max(cur_step / self.focus_steps, 0.0), 1.0) if self.focus_steps > 0 else 0.0
-        loss_mean = loss_raw.reshape(BT, -1).mean(dim=1)
+        loss_mean = loss_all.reshape(BT, -1).mean(dim=1)
         cur_top = (1.0 - progress) + self.focus_top * progress
         if cur_top < 1.0:
-            flat = loss_raw.reshape(BT, -1)
+            flat = loss_all.reshape(BT, -1)
             keep = int(flat.shape[1] * cur_top)
             loss_focal = flat.topk(keep, dim=1)[0].mean(dim=1) * 0.9 + loss_mean * 0.1
         else:
             loss_focal = loss_mean
-        return loss_focal * w.flatten()
+        return (loss_focal + bias_mean * 0.5) * w.flatten()
 
 
 # ------------------------------------------------------------------------------------------------

@@ -44,10 +44,36 @@ def test_get_loss_vs_reference_known_answers(g):
         ora = R.get_loss(g["out"], g["tgt"], w, case["step"], case["loss_type"], 0.1, 5000)
         assert torch.allclose(got, case["loss"], rtol=1e-6, atol=0), case
         assert torch.allclose(ora, case["loss"], rtol=1e-6, atol=0), case
-    with pytest.raises(NotImplementedError):
-        StandardDiffusionLoss(**dict(CFG, pd_person_weight=2.0)).get_loss(g["out"], g["tgt"], w, {"global_step": 0})
     with pytest.raises(AssertionError):
         StandardDiffusionLoss(**dict(CFG, loss_type="huber"))
+
+
+def test_get_loss_parallel_domain_class_weights_vs_reference_known_answers():
+    """loss.py:196-230 (configs/train_pardom_semantic.yaml:145-146: person x7, vehicle x3): semantic-map colours ->
+    area-averaged latent masks -> half of the weighted loss before the focal top-fraction, half after.  Known answers
+    from the unmodified reference get_loss (oracle/make_golden_loss.py pd) for person+vehicle / person only / vehicle
+    only, L2 / L1, before / inside / after the focal annealing window; product and oracle."""
+    from oracle.make_golden_loss import pd_semantic_frames
+    from gcd_amd.training import StandardDiffusionLoss
+    g = torch.load(GOLD.parent / "loss_pd_kat.pt")
+    jpg = pd_semantic_frames(g["out"].shape[0], *g["jpg_hw"], seed=g["jpg_seed"])
+    w = g["weights"][:, None, None, None]
+    assert len(g["cases"]) == 18
+    for case in g["cases"]:
+        loss = StandardDiffusionLoss(**dict(CFG, loss_type=case["loss_type"], pd_person_weight=case["person"],
+                                            pd_vehicle_weight=case["vehicle"]))
+        got = loss.get_loss(g["out"], g["tgt"], w, {"global_step": case["step"], "jpg": jpg})
+        ora = R.get_loss_pd(g["out"], g["tgt"], w, case["step"], jpg, case["person"], case["vehicle"],
+                            case["loss_type"], 0.1, 5000)
+        assert torch.allclose(got, case["loss"], rtol=2e-6, atol=0), case
+        assert torch.allclose(ora, case["loss"], rtol=2e-6, atol=0), case
+    # the weighting changes the loss (the fixture paints pedestrians / cars into every frame), and it is differentiable
+    plain = StandardDiffusionLoss(**CFG).get_loss(g["out"], g["tgt"], w, {"global_step": 1})
+    assert float((g["cases"][0]["loss"] / plain).min()) > 1.01
+    out = g["out"].clone().requires_grad_(True)
+    StandardDiffusionLoss(**dict(CFG, pd_person_weight=7.0, pd_vehicle_weight=3.0)).get_loss(
+        out, g["tgt"], w, {"global_step": 2501, "jpg": jpg}).sum().backward()
+    assert bool(torch.isfinite(out.grad).all()) and float(out.grad.abs().sum()) > 0
 
 
 def test_forward_plumbing_vs_reference(g):
