@@ -449,7 +449,9 @@ class AdamHIP:
             ops._need_gpu(*ps[:1], *gs[:1])
             arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])      # noqa: E731
             # parameter / moment addresses do not change between steps: their pointer tables are built once
-            key = tuple(id(t) for t in ps)
+            # keyed on the storage addresses themselves (the `p.data` wrappers above are temporaries whose ids recycle;
+            # a resume that re-assigns `state` or moves a parameter must rebuild the tables)
+            key = tuple((t.data_ptr(), m_.data_ptr(), v_.data_ptr()) for t, m_, v_ in zip(ps, ms, vs))
             if self._tables is None or self._tables[0] != key:
                 self._tables = (key, arr(ps), arr(ms), arr(vs), (C.c_int64 * n)(*[t.numel() for t in ps]))
             _, ap, am, av, numel = self._tables
@@ -474,11 +476,21 @@ class GradBucketer:
         bucketer.finish()                                      # wait, average, write back; then optimizer step
 
     Parameters are bucketed in REVERSE registration order (the order the backward pass reaches them, output blocks
-    first).  A parameter the graph never reaches (attn2.to_q / to_k / norm2 behind the one-key cross-attention) never
-    fires its hook: `finish()` enters zeros for it, so every rank reduces the same buffers whatever its graph reached.
+    first).  A parameter the graph never reaches (attn2.to_q / to_k / norm2 behind the one-key cross-attention: three
+    in every SpatialVideoTransformer block, so nearly every 256 MB bucket of the VideoUNet holds one) never fires its
+    hook.  Such parameters count as ready from the start — the ones named in `unused`, plus (static_graph, what DDP
+    calls it) the ones the FIRST synchronised backward pass did not reach — and enter their bucket as zeros, so every
+    rank reduces the same buffers whatever its graph reached and every bucket still launches DURING the backward pass.
+    If a parameter recorded as unused does fire later, its bucket is re-launched in `finish()` with the real gradient.
+
+    Gradient accumulation (accumulate_grad_batches, main.py:950): run the first micro-batches under `no_sync()` — hooks
+    are ignored, torch accumulates into p.grad — and the last one outside it: buckets pack the ACCUMULATED p.grad the
+    moment the last micro-batch's hook fires.  A second synchronised backward() before finish() would reduce a stale
+    first micro-batch; it raises instead.
     Results equal `allreduce_gradients` (mean over ranks); gloo world-2 test in tests/test_training_host.py."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], dist=None, group=None, bucket_bytes: int = 256 << 20):
+    def __init__(self, params: Iterable[torch.nn.Parameter], dist=None, group=None, bucket_bytes: int = 256 << 20,
+                 unused: Optional[Iterable[torch.nn.Parameter]] = None, static_graph: bool = True):
         self.dist, self.group = dist, group
         self.active = dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1
         self.world = dist.get_world_size(group) if self.active else 1
@@ -494,14 +506,36 @@ class GradBucketer:
             size += nb
         self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
         self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
+        self._unused = {id(p) for p in (unused or ()) if id(p) in self._bucket_of}
+        self._learn_unused = static_graph
         self._ready = [0] * len(self.buckets)
         self._seen = set()
+        self._late = set()       # buckets launched without a gradient that arrived afterwards
         self._work: List[Optional[object]] = [None] * len(self.buckets)
+        self._sync = True
         self.launched_during_backward = 0
         self._hooks = []
+        self._reset_ready()
         if self.active:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _reset_ready(self) -> None:
+        for i, b in enumerate(self.buckets):
+            self._ready[i] = sum(1 for p in b if id(p) in self._unused)
+
+    def no_sync(self):
+        """Context manager for the non-final micro-batches of gradient accumulation: hooks are ignored."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old, self._sync = self._sync, False
+            try:
+                yield self
+            finally:
+                self._sync = old
+        return ctx()
 
     def _launch(self, i: int) -> None:
         b = self.buckets[i]
@@ -520,20 +554,38 @@ class GradBucketer:
         self._work[i] = self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p: torch.nn.Parameter) -> None:
-        if id(p) in self._seen:            # a second accumulation into the same parameter in one backward pass
+        if not self._sync:
+            return
+        i = self._bucket_of[id(p)]
+        if id(p) in self._seen:
+            # a second firing between two finish() calls: a shared parameter accumulating twice inside one backward
+            # pass is harmless while its bucket still waits, but once the bucket is in flight the reduction has
+            # already read the first value — that is a second backward() without no_sync() / finish()
+            if self._work[i] is not None:
+                raise RuntimeError("GradBucketer: a gradient arrived for a bucket whose all-reduce is already in "
+                                   "flight — run all but the last micro-batch under bucketer.no_sync(), and call "
+                                   "finish() after every synchronised backward()")
             return
         self._seen.add(id(p))
-        i = self._bucket_of[id(p)]
+        if id(p) in self._unused:          # recorded as unreached, but this graph reached it
+            self._unused.discard(id(p))
+            if self._work[i] is not None:
+                self._late.add(i)          # its bucket left with zeros: finish() reduces it again
+            return
         self._ready[i] += 1
         if self._ready[i] == len(self.buckets[i]) and self._work[i] is None:
             self._launch(i)
             self.launched_during_backward += 1
 
     def finish(self) -> int:
-        """Launch what the backward pass did not complete (buckets holding unreached parameters), wait for every
-        bucket, write the averaged gradients back.  Returns the number of buckets."""
+        """Launch what the backward pass did not complete (buckets holding parameters not yet known to be unreached),
+        wait for every bucket, write the averaged gradients back.  Returns the number of buckets."""
         if not self.active:
             return 0
+        for i in sorted(self._late):       # same order on every rank only if the graphs agree; they do under DDP's
+            self._work[i].wait()           # own contract (every rank runs the same module)
+            self._launch(i)
+        self._late.clear()
         for i in range(len(self.buckets)):
             if self._work[i] is None:
                 self._launch(i)
@@ -551,8 +603,11 @@ class GradBucketer:
                     p.grad.copy_(g)
                 off += n
             self._work[i] = None
-            self._ready[i] = 0
+        if self._learn_unused:             # static graph: what this pass did not reach stays unreached
+            self._unused |= {id(p) for p in self.params if id(p) not in self._seen}
+            self._learn_unused = False
         self._seen.clear()
+        self._reset_ready()
         return len(self.buckets)
 
     def close(self) -> None:

@@ -183,6 +183,104 @@ def test_grad_bucketer_overlapped_allreduce_gloo_world2():
     assert gloo_util.run_world(_bucketer_worker, 2) == {0: True, 1: True}
 
 
+def _bucketer_unused_worker(rank, world, port, q):
+    """(a) unreached parameters inside EVERY bucket (the attn2.to_q / to_k / norm2 pattern of the VideoUNet)
+    must not push the launches into finish(): named up front, or learned from the first pass, every bucket launches
+    during backward; a parameter recorded as unreached that later IS reached still ends up with the right mean.
+    (b) gradient accumulation: micro-batches under no_sync() + a last synchronised one == the mean over ranks of the
+    summed micro-batch gradients; a second synchronised backward() without finish() raises."""
+    from gcd_amd.training import GradBucketer, allreduce_gradients
+    gloo_util.init(rank, world, port)
+    try:
+        torch.manual_seed(0)
+        blocks = torch.nn.ModuleList([torch.nn.Linear(24, 24) for _ in range(6)])
+        dead = torch.nn.ModuleList([torch.nn.Linear(24, 24) for _ in range(6)])      # one unreached layer per block
+        params = []
+        for blk, dd in zip(blocks, dead):
+            params += list(blk.parameters()) + list(dd.parameters())
+
+        def fwd(x, use_dead=None):
+            for i, blk in enumerate(blocks):
+                x = torch.tanh(blk(x))
+                if use_dead is not None and i == use_dead:
+                    x = x + 0.1 * dead[i](x)
+            return x
+
+        g = torch.Generator().manual_seed(200 + rank)
+        xs = [torch.randn(16, 24, generator=g) for _ in range(3)]
+
+        def reference(batches, use_dead=None):
+            for p in params:
+                p.grad = None
+            for x in batches:
+                (fwd(x, use_dead) ** 2).mean().backward()
+            allreduce_gradients(params, dist, bucket_bytes=5000)
+            want = [p.grad.clone() for p in params]
+            for p in params:
+                p.grad = None
+            return want
+
+        # every reference first: no bucketer (and none of its hooks) exists yet
+        want1, want_dead, want_acc = reference(xs[:1]), reference(xs[1:2], use_dead=2), reference(xs)
+        ok = True
+        # (a1) learned: step 1 leaves the buckets with dead layers to finish(); from step 2 on all launch in backward
+        b = GradBucketer(params, dist, bucket_bytes=5000)
+        nb = len(b.buckets)
+        ok = ok and nb >= 4
+        (fwd(xs[0]) ** 2).mean().backward()
+        first = b.launched_during_backward
+        b.finish()
+        ok = ok and first < nb and all(torch.equal(p.grad, w) for p, w in zip(params, want1))
+        for p in params:
+            p.grad = None
+        (fwd(xs[0]) ** 2).mean().backward()
+        ok = ok and b.launched_during_backward - first == nb
+        b.finish()
+        ok = ok and all(torch.equal(p.grad, w) for p, w in zip(params, want1))
+        # a layer recorded as unreached is reached now: its bucket left with zeros and is reduced again in finish()
+        for p in params:
+            p.grad = None
+        (fwd(xs[1], use_dead=2) ** 2).mean().backward()
+        b.finish()
+        ok = ok and all(torch.equal(p.grad, w) for p, w in zip(params, want_dead))
+        ok = ok and float(dead[2].weight.grad.abs().max()) > 0
+        b.close()
+        # (a2) named up front: every bucket launches during the very first backward
+        for p in params:
+            p.grad = None
+        b = GradBucketer(params, dist, bucket_bytes=5000, unused=[q_ for dd in dead for q_ in dd.parameters()])
+        (fwd(xs[0]) ** 2).mean().backward()
+        ok = ok and b.launched_during_backward == nb
+        b.finish()
+        ok = ok and all(torch.equal(p.grad, w) for p, w in zip(params, want1))
+        # (b) accumulation over three micro-batches
+        for p in params:
+            p.grad = None
+        with b.no_sync():
+            (fwd(xs[0]) ** 2).mean().backward()
+            (fwd(xs[1]) ** 2).mean().backward()
+        (fwd(xs[2]) ** 2).mean().backward()
+        b.finish()
+        ok = ok and all(torch.allclose(p.grad, w, rtol=1e-6, atol=1e-9) for p, w in zip(params, want_acc))
+        for p in params:
+            p.grad = None
+        (fwd(xs[0]) ** 2).mean().backward()
+        raised = False
+        try:
+            (fwd(xs[1]) ** 2).mean().backward()
+        except RuntimeError as e:
+            raised = "no_sync" in str(e)
+        b.finish()
+        b.close()
+        q.put((rank, bool(ok and raised)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_bucketer_unreached_parameters_and_accumulation_gloo_world2():
+    assert gloo_util.run_world(_bucketer_unused_worker, 2) == {0: True, 1: True}
+
+
 def test_grad_bucketer_single_process_is_inert():
     from gcd_amd.training import GradBucketer
     p = torch.nn.Parameter(torch.zeros(3))
