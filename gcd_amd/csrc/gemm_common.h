@@ -46,6 +46,9 @@ struct GemmK {
   float* colstats;
   int out_blocked, a_blocked;   // tile-blocked GEGLU hidden tensor (gcd_gemm_desc.out_blocked / a_blocked)
   int operand_bf16;             // A and W are bfloat16 (general kernel, PLAIN mode, fp32 output)
+  // gemm_p8.hip: operand extents in bytes (buffer descriptors), frames of a conv input
+  uint32_t a_bytes, w_bytes;
+  int a_frames;
 };
 
 // gemm_pp.hip: the 256 x 320 ping-pong kernel.
@@ -175,6 +178,106 @@ __device__ __forceinline__ void gcd_epilogue_64x160_ln(const GemmK& p, f32x16 (&
 }
 
 // ------------------------------------------------------------------------------------------------
+// The two accumulator layouts of a wave's 64 x 160 tile, and the helpers that hide them from the
+// row-major epilogues below (the read-back side of every staged path is layout independent):
+//   GcdAcc32 (gemm_pp.hip, v_mfma_f32_32x32x16):  acc[i][j][4g + e] = C[32 j + l31][32 i + 8 g + 4 hh + e]
+//   GcdAcc16 (gemm_p8.hip, v_mfma_f32_16x16x32):  acc[c][t][e]      = C[16 t + (lane & 15)][16 c + 4 (lane >> 4) + e]
+// GEGLU weight rows are interleaved 16 value / 16 gate per 32-row block (packing.pack_geglu): value and gate
+// of one output live in the same lane in both layouts (registers 4g+e / 8+4g+e, blocks 2i / 2i+1).
+// ------------------------------------------------------------------------------------------------
+typedef f32x16 GcdAcc32[5][2];
+typedef f32x4 GcdAcc16[10][4];
+
+// 32 x 32 sub-tile (column block i, token half j) -> `stage` as row-major fp32 rows of GCD_EPI_ROW_F32 bytes
+__device__ __forceinline__ void gcd_stage_tile32(const GcdAcc32& acc, int i, int j, char* stage, int lane) {
+  char* const wr = stage + (lane & 31) * GCD_EPI_ROW_F32 + (lane >> 5) * 16;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+    *(f32x4*)(wr + g * 32) = v;
+  }
+}
+__device__ __forceinline__ void gcd_stage_tile32(const GcdAcc16& acc, int i, int j, char* stage, int lane) {
+  char* const wr = stage + (lane & 15) * GCD_EPI_ROW_F32 + (lane >> 4) * 16;
+#pragma unroll
+  for (int th = 0; th < 2; ++th)
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) *(f32x4*)(wr + th * 16 * GCD_EPI_ROW_F32 + ch * 64) = acc[2 * i + ch][2 * j + th];
+}
+
+// GEGLU: token half j of the wave tile -> `stage` as fp16 [32][80] rows of GCD_EPI_ROW_F16 bytes
+// (lbl = the wave's 160 staged per-column addends)
+__device__ __forceinline__ void gcd_stage_geglu_half(const GcdAcc32& acc, int j, const float* lb, char* stage, int lane) {
+  const int l31 = lane & 31, hh = lane >> 5;
+  const float* lbl = lb + 4 * hh;
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const f32x4 ba = *(const f32x4*)(lbl + 32 * i + 8 * g);
+      const f32x4 bg = *(const f32x4*)(lbl + 32 * i + 16 + 8 * g);
+      f16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        o[e] = (f16)((acc[i][j][4 * g + e] + ba[e]) * gelu_fast(acc[i][j][8 + 4 * g + e] + bg[e]));
+      *(f16x4*)(stage + l31 * GCD_EPI_ROW_F16 + (16 * i + 8 * g + 4 * hh) * 2) = o;
+    }
+}
+__device__ __forceinline__ void gcd_stage_geglu_half(const GcdAcc16& acc, int j, const float* lb, char* stage, int lane) {
+  const int r15 = lane & 15, q = lane >> 4;
+  const float* lbl = lb + 4 * q;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const f32x4 ba = *(const f32x4*)(lbl + 32 * i);
+    const f32x4 bg = *(const f32x4*)(lbl + 32 * i + 16);
+#pragma unroll
+    for (int th = 0; th < 2; ++th) {
+      f16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        o[e] = (f16)((acc[2 * i][2 * j + th][e] + ba[e]) * gelu_fast(acc[2 * i + 1][2 * j + th][e] + bg[e]));
+      *(f16x4*)(stage + (16 * th + r15) * GCD_EPI_ROW_F16 + (16 * i + 4 * q) * 2) = o;
+    }
+  }
+}
+
+// fp16 output without residuals: token half j -> `stage` as fp16 [32][160] rows of GCD_EPI_ROW_H160 bytes
+#define GCD_EPI_ROW_H160 336
+__device__ __forceinline__ void gcd_stage_f16_half(const GcdAcc32& acc, int j, const float* lb, float sa, char* stage,
+                                                   int lane) {
+  const int l31 = lane & 31, hh = lane >> 5;
+  const float* lbl = lb + 4 * hh;
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bv = *(const f32x4*)(lbl + 32 * i + 8 * g);
+      f16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (f16)((acc[i][j][4 * g + e] + bv[e]) * sa);
+      *(f16x4*)(stage + l31 * GCD_EPI_ROW_H160 + (32 * i + 8 * g + 4 * hh) * 2) = o;
+    }
+}
+__device__ __forceinline__ void gcd_stage_f16_half(const GcdAcc16& acc, int j, const float* lb, float sa, char* stage,
+                                                   int lane) {
+  const int r15 = lane & 15, q = lane >> 4;
+  const float* lbl = lb + 4 * q;
+#pragma unroll
+  for (int c = 0; c < 10; ++c) {
+    const f32x4 bv = *(const f32x4*)(lbl + 16 * c);
+#pragma unroll
+    for (int th = 0; th < 2; ++th) {
+      f16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (f16)((acc[c][2 * j + th][e] + bv[e]) * sa);
+      *(f16x4*)(stage + (16 * th + r15) * GCD_EPI_ROW_H160 + (16 * c + 4 * q) * 2) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Pipelined epilogues for a FULL 64 x 160 wave tile (every row < M, every column < N).
 //
 // The generic epilogue further below issues one residual load, waits for it (s_waitcnt vmcnt(0),
@@ -219,12 +322,12 @@ __device__ __forceinline__ float gcd_sum_lane_bits_345(float a) {
 // write them to p.colstats — a lane owns 4 fixed channels of every 32-column block and 8 of its rows
 // (rr + 8 qq + 32 j), so one block costs 8 adds + 8 FMAs per lane on values it holds anyway, then an
 // 8-lane tree over the lanes that share those channels (lane bits 3-5).
-template <bool HAS_R1, bool HAS_R2, bool OUT16 = false, bool STATS = false>
-__device__ __forceinline__ void gcd_epi_f32_rows_full(const GemmK& p, f32x16 (&acc)[5][2], int m_base,
+template <bool HAS_R1, bool HAS_R2, bool OUT16 = false, bool STATS = false, typename ACC = GcdAcc32>
+__device__ __forceinline__ void gcd_epi_f32_rows_full(const GemmK& p, ACC& acc, int m_base,
                                                      int n_base, int lane, const float* lb, char* stage,
                                                      float sa, float sr1, float sr2) {
   constexpr int D = HAS_R2 ? 1 : 2;
-  const int l31 = lane & 31, hh = lane >> 5, rr = lane >> 3, cc = (lane & 7) * 4;
+  const int rr = lane >> 3, cc = (lane & 7) * 4;
   const int64_t col = n_base + cc;
   // OUT16: the same pipeline with an fp16 result (the last temporal FF of a transformer, whose blended
   // output only feeds proj_out): 8 rows x 64 B per store instruction
@@ -233,7 +336,6 @@ __device__ __forceinline__ void gcd_epi_f32_rows_full(const GemmK& p, f32x16 (&a
   const float* const r1p = HAS_R1 ? p.R1 + (int64_t)(m_base + rr) * p.ldr1 + col : nullptr;
   const float* const r2p = HAS_R2 ? p.R2 + (int64_t)(m_base + rr) * p.ldr2 + col : nullptr;
   const int64_t so = 8 * p.ldo, s1 = 8 * p.ldr1, s2 = 8 * p.ldr2;
-  char* const wr = stage + l31 * GCD_EPI_ROW_F32 + hh * 16;
   const char* const rd = stage + rr * GCD_EPI_ROW_F32 + cc * 4;
   f32x4 q1[D][4], q2[D][4];
   auto fetch = [&](int b, int slot) {   // tile b = (column block b >> 1, token half b & 1)
@@ -252,13 +354,7 @@ __device__ __forceinline__ void gcd_epi_f32_rows_full(const GemmK& p, f32x16 (&a
 #pragma unroll
   for (int b = 0; b < 10; ++b) {
     const int i = b >> 1, j = b & 1;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-      *(f32x4*)(wr + g * 32) = v;
-    }
+    gcd_stage_tile32(acc, i, j, stage, lane);
     const f32x4 bv = *(const f32x4*)(lb + 32 * i + cc);
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
@@ -306,10 +402,9 @@ __device__ __forceinline__ void gcd_epi_f32_rows_full(const GemmK& p, f32x16 (&a
 // ([32][80] + 16 B row pad, twice) and leave as 16-byte pieces of 160-byte row segments: 6.4 rows per store
 // instruction instead of 32 rows x 16 B straight from the accumulator layout, and half as many store
 // instructions (measured -3..-7 % per GEGLU launch, profiles/r01q_gemm_bench_rows.txt).
-__device__ __forceinline__ void gcd_epi_geglu_rows_full(const GemmK& p, f32x16 (&acc)[5][2], int m_base,
+template <typename ACC>
+__device__ __forceinline__ void gcd_epi_geglu_rows_full(const GemmK& p, ACC& acc, int m_base,
                                                         int n_base, int lane, const float* lb, char* stage) {
-  const int l31 = lane & 31, hh = lane >> 5;
-  const float* lbl = lb + 4 * hh;
   // row-major [M, N/2], or tile-blocked: tile (tm, tn) = one contiguous [256][160] block (out_blocked)
   f16* outp = (f16*)p.out + (int64_t)m_base * p.ldo + (n_base >> 1);
   int64_t rs = p.ldo;
@@ -322,18 +417,7 @@ __device__ __forceinline__ void gcd_epi_geglu_rows_full(const GemmK& p, f32x16 (
   // one 32-token half at a time (5.5 KB of stage): the stores of half 0 drain under the GELU of half 1
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        const f32x4 ba = *(const f32x4*)(lbl + 32 * i + 8 * g);
-        const f32x4 bg = *(const f32x4*)(lbl + 32 * i + 16 + 8 * g);
-        f16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          o[e] = (f16)((acc[i][j][4 * g + e] + ba[e]) * gelu_fast(acc[i][j][8 + 4 * g + e] + bg[e]));
-        *(f16x4*)(stage + l31 * GCD_EPI_ROW_F16 + (16 * i + 8 * g + 4 * hh) * 2) = o;
-      }
+    gcd_stage_geglu_half(acc, j, lb, stage, lane);
 #pragma unroll
     for (int it = 0; it < 5; ++it) {
       const int tt = it * 64 + lane;
@@ -347,24 +431,13 @@ __device__ __forceinline__ void gcd_epi_geglu_rows_full(const GemmK& p, f32x16 (
 // fp16 outputs without residuals (the q|k|v projections): each 32-token half of the wave tile is
 // staged as fp16 [32][160] (+16 B row pad) and leaves as 16-byte pieces of 320-byte row segments — 3.2
 // rows per store instruction, against 8 rows x 64 B through the generic fp32-staged path below.
-#define GCD_EPI_ROW_H160 336
-__device__ __forceinline__ void gcd_epi_f16_rows_full(const GemmK& p, f32x16 (&acc)[5][2], int m_base,
+template <typename ACC>
+__device__ __forceinline__ void gcd_epi_f16_rows_full(const GemmK& p, ACC& acc, int m_base,
                                                       int n_base, int lane, const float* lb, char* stage) {
-  const int l31 = lane & 31, hh = lane >> 5;
-  const float* lbl = lb + 4 * hh;
   const float sa = p.s_acc;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 bv = *(const f32x4*)(lbl + 32 * i + 8 * g);
-        f16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (f16)((acc[i][j][4 * g + e] + bv[e]) * sa);
-        *(f16x4*)(stage + l31 * GCD_EPI_ROW_H160 + (32 * i + 8 * g + 4 * hh) * 2) = o;
-      }
+    gcd_stage_f16_half(acc, j, lb, sa, stage, lane);
     f16* const outp = (f16*)p.out + (int64_t)(m_base + 32 * j) * p.ldo + n_base;
 #pragma unroll
     for (int it = 0; it < 10; ++it) {
@@ -517,5 +590,66 @@ __device__ __forceinline__ void gcd_epilogue_64x160(const GemmK& p, f32x16 (&acc
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read-back done before the next overwrite
+  }
+}
+
+// The generic epilogue for the 16x16x32 accumulator layout (gemm_p8.hip): ragged edge tiles, a rowvec / alpha that
+// changes inside a tile, fp16 outputs with residuals, split-K partial sums — direct stores from the accumulator layout
+// (16 rows x 64 B fp32 per instruction).  Full tiles take the row-major fast paths above.
+__device__ __forceinline__ void gcd_epilogue_64x160(const GemmK& p, GcdAcc16& acc, int m_base, int n_base, int lane) {
+  const int r15 = lane & 15, q = lane >> 4;
+  if (p.out_kind == GCD_OUT_GEGLU) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int m = m_base + 16 * t + r15;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int nb = n_base + 32 * i;
+        if (nb >= p.N) continue;
+        f32x4 a = acc[2 * i][t], gt = acc[2 * i + 1][t];
+        if (p.bias) {
+          a += *(const f32x4*)(p.bias + nb + 4 * q);
+          gt += *(const f32x4*)(p.bias + nb + 16 + 4 * q);
+        }
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (f16)(a[e] * gelu_fast(gt[e]));
+        *(f16x4*)((f16*)p.out + (int64_t)m * p.ldo + (nb >> 1) + 4 * q) = o;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int m = m_base + 16 * t + r15;
+    if (m >= p.M) continue;
+    float sa = p.s_acc, sr1 = p.s_r1, sr2 = p.s_r2;
+    if (p.frame_alpha) {
+      const float al = p.frame_alpha[m / p.rows_per_alpha];
+      sa = 1.0f - al;
+      sr2 = al;
+      if (p.r1_blend) sr1 *= 1.0f - al;
+    }
+    const float* rv = p.rowvec ? p.rowvec + (int64_t)(m / p.rows_per_vec) * p.ld_rowvec : nullptr;
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+      const int n = n_base + 16 * c + 4 * q;
+      if (n >= p.N) continue;
+      f32x4 v = acc[c][t];
+      if (p.bias) v += *(const f32x4*)(p.bias + n);
+      if (rv) v += *(const f32x4*)(rv + n);
+      v *= sa;
+      if (p.R1) v += sr1 * *(const f32x4*)(p.R1 + (int64_t)m * p.ldr1 + n);
+      if (p.R2) v += sr2 * *(const f32x4*)(p.R2 + (int64_t)m * p.ldr2 + n);
+      if (p.out_kind == GCD_OUT_F32) {
+        *(f32x4*)((float*)p.out + (int64_t)m * p.ldo + n) = v;
+      } else {
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (f16)v[e];
+        *(f16x4*)((f16*)p.out + (int64_t)m * p.ldo + n) = o;
+      }
+    }
   }
 }

@@ -549,6 +549,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmK p, const
   }
 }
 
+static int launch_splitk_reduce(const GemmK& k, int splitk, const float* ws, hipStream_t s) {
+  GemmK kr = k;
+  kr.split_stride = (int64_t)k.M * k.N;
+  const int64_t nvec = (int64_t)k.M * (k.N >> 2);
+  int64_t rb = (nvec + 255) / 256;
+  if (rb > 4096) rb = 4096;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, s, kr, ws, splitk);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int MODE, int BF = 0>
 int launch_pp_splitk(const GemmK& k, int splitk, float* ws, hipStream_t s) {
   static GcdPerDeviceOnce attr_once;
@@ -569,19 +580,21 @@ int launch_pp_splitk(const GemmK& k, int splitk, float* ws, hipStream_t s) {
   const int64_t nblk = (int64_t)kk.tiles_m * kk.tiles_n * splitk;
   hipLaunchKernelGGL(fn, dim3((unsigned)nblk), dim3(512), PP_SMEM_LAUNCH, s, kk);
   GCD_CHECK_LAUNCH();
-  GemmK kr = k;
-  kr.split_stride = kk.split_stride;
-  const int64_t nvec = (int64_t)k.M * (k.N >> 2);
-  int64_t rb = (nvec + 255) / 256;
-  if (rb > 4096) rb = 4096;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, s, kr, ws, splitk);
-  GCD_CHECK_LAUNCH();
-  return 0;
+  return launch_splitk_reduce(k, splitk, ws, s);
 }
 
 }  // namespace
 
+// gemm_p8.hip: the 8-phase 16x16x32 K loop on the same tile (GCD_TUNE_GEMM_IMPL = 3 keeps this file's ring kernel)
+bool gcd_gemm_p8_supported(const GemmK& k, int mode);
+int gcd_gemm_p8_launch(const GemmK& k, int mode, bool persist, hipStream_t s);
+int gcd_gemm_p8_launch_splitk(const GemmK& k, int mode, int splitk, float* ws, hipStream_t s);
+
 int gcd_gemm_pp_launch_splitk(const GemmK& k, int mode, int splitk, float* ws, hipStream_t s) {
+  if (gcd_tune_get(GCD_TUNE_GEMM_IMPL) != 3 && gcd_gemm_p8_supported(k, mode)) {
+    if (const int rc = gcd_gemm_p8_launch_splitk(k, mode, splitk, ws, s)) return rc;
+    return launch_splitk_reduce(k, splitk, ws, s);
+  }
   if (k.operand_bf16) {
     switch (mode) {
       case GCD_GEMM_PLAIN:
@@ -642,6 +655,9 @@ int gcd_gemm_pp_launch(const GemmK& k, int mode, hipStream_t s) {
   // teardown, 6-7 % on the K = 320 / 640 shapes); otherwise one workgroup per tile.
   const int64_t tiles = (int64_t)((k.M + PP_BM - 1) / PP_BM) * ((k.N + PP_BN - 1) / PP_BN);
   const bool persist = tiles > 256 && gcd_tune_get(GCD_TUNE_GEMM_IMPL) != 4;   // knob 4: never persistent
+  // the 8-phase K loop (gemm_p8.hip) wherever it applies; knob 3 keeps this file's 32-deep ring kernel
+  if (gcd_tune_get(GCD_TUNE_GEMM_IMPL) != 3 && gcd_gemm_p8_supported(k, mode))
+    return gcd_gemm_p8_launch(k, mode, persist, s);
   if (k.ln_out) {   // validated by gcd_gemm_f16: PLAIN mode, N == 320
     if (mode != GCD_GEMM_PLAIN) {
       gcd_set_error("gcd_gemm_f16: fused LayerNorm is implemented for GCD_GEMM_PLAIN only");

@@ -9,7 +9,22 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-def init(rank: int, world: int, store_path: str, backend: str = "gloo") -> None:
+def backend_name() -> str:
+    """gloo (default; CPU tests and the two-ranks-on-one-GPU tests) or, on a multi-GPU node, GCD_DIST_BACKEND=nccl
+    (= RCCL; tools/first_multi_gpu.sh)."""
+    return os.environ.get("GCD_DIST_BACKEND", "gloo")
+
+
+def rank_device(rank: int):
+    """cuda:0 for every rank (one-GPU lease) unless GCD_TEST_GPUS_PER_RANK=1 gives each rank its own GPU."""
+    import torch
+    if os.environ.get("GCD_TEST_GPUS_PER_RANK") == "1":
+        return torch.device(f"cuda:{rank % torch.cuda.device_count()}")
+    return torch.device("cuda:0")
+
+
+def init(rank: int, world: int, store_path: str, backend: str = None) -> None:
+    backend = backend or backend_name()
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # the container hostname may not resolve
     dist.init_process_group(backend, store=dist.FileStore(store_path, world), rank=rank, world_size=world)
 

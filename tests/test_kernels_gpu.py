@@ -26,10 +26,11 @@ def _gen(seed):
     return torch.Generator().manual_seed(seed)
 
 
-@pytest.fixture(params=[0, 2, 6], ids=["auto", "pingpong", "tile64"], autouse=True)
+@pytest.fixture(params=[0, 2, 3, 6], ids=["auto", "tile256x320", "ring32", "tile64"], autouse=True)
 def gemm_impl(request):
-    """Every test of this module runs with the automatic GEMM kernel choice, with the 256x320
-    ping-pong kernel forced and with the general kernel's 64-row tiles forced."""
+    """Every test of this module runs with the automatic GEMM kernel choice, with the 256x320 tile kernels forced
+    (2: the 8-phase 16x16x32 K loop of gemm_p8.hip wherever it applies; 3: the 32-deep ring kernel of gemm_pp.hip
+    only) and with the general kernel's 64-row tiles forced."""
     from gcd_amd import ops
     ops.tune_set(ops.TUNE_GEMM_IMPL, request.param)
     yield request.param

@@ -48,10 +48,10 @@ def _sampler_and_net(dev):
 def _worker(rank, world, store, num_clips, q):
     import torch.distributed as dist
     from gcd_amd import parallel
+    dev = gloo_util.rank_device(rank)
+    torch.cuda.set_device(dev)
     gloo_util.init(rank, world, store)
     try:
-        dev = torch.device("cuda:0")
-        torch.cuda.set_device(dev)
         one = _sampler_and_net(dev)
         got = parallel.sample_clips(one, num_clips, dist, base_seed=900, device=dev)
         ok = len(got) == num_clips and all(t is not None and t.shape == (14, 4, 8, 8) for t in got)
@@ -106,10 +106,10 @@ def _train_setup(dev, seed):
 def _ddp_worker(rank, world, store, q):
     import torch.distributed as dist
     from gcd_amd import training as TR
+    dev = gloo_util.rank_device(rank)
+    torch.cuda.set_device(dev)
     gloo_util.init(rank, world, store)
     try:
-        dev = torch.device("cuda:0")
-        torch.cuda.set_device(dev)
         net, mine, loss_of = _train_setup(dev, 500 + rank)
         bucketer = TR.GradBucketer(net.parameters(), dist, bucket_bytes=1 << 20)
         (loss_of(mine) * 256.0).backward()
@@ -137,7 +137,9 @@ def _ddp_worker(rank, world, store, q):
         opt = TR.AdamHIP(net.parameters(), lr=1e-4)
         opt.step(grad_scale=1.0 / 256.0)
         torch.cuda.synchronize()
-        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu()
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        if gloo_util.backend_name() != "nccl":
+            flat = flat.cpu()
         gathered = [torch.empty_like(flat) for _ in range(world)]
         dist.all_gather(gathered, flat)
         ok = ok and all(torch.equal(gathered[0], t) for t in gathered[1:])
