@@ -66,7 +66,14 @@ constexpr int P8_GROUP_M = 4;
 
 // VAR bits: 2048 persistent (256 workgroups walk the tiles), 4096 per-64-row column statistics (gcd_gemm_desc.colstats),
 // 16384 split-K (raw fp32 partial sums of K slice L % splitk).
-template <int MODE, int VAR>
+// Ablation bits (GCD_ABLATION_BUILD only, tools/gemm_bench_ablate; wrong results by design except 4 and 8):
+//   1 no epilogue   2 no K loop (epilogue of zeros)   4 LDS-only barrier at the end of a tile (stores and the
+//   prefetched K-tile stay in flight)   8 no cross-tile prefetch
+// EPI: which full-tile fast path of the epilogue this instantiation carries (the generic direct path is always there,
+// for ragged tiles): 0 all of them (run-time choice per tile), 1 GEGLU, 2 fp16 rows without residuals, 3 fp32 rows
+// with at most the first residual, 4 fp32 rows with both residuals (AlphaBlender), 5 fp16 rows with both residuals.  One path per kernel keeps the tile boundary free of register spills (whose reloads
+// wait vmcnt(0) and thereby drain the epilogue's stores and the prefetched K-tile).
+template <int MODE, int VAR, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
@@ -181,6 +188,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
       s_begin = kz * per;
       nK = max(0, min(per, nK - s_begin));
     }
+    if (VAR & 2) nK = 0;
     if (MODE == GCD_GEMM_PLAIN) {
       const int g = 2 * wave;
       const int m = m0 + 64 * (g >> 2) + 8 * (g & 3) + lrow;
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
   // Cross-tile prefetch (persistent PLAIN kernels, as gemm_pp.hip): the NEXT tile's set_tile + K-tile 0 are issued
   // BEFORE the epilogue (buffer 0 is not staging space); the first counted wait of the next K loop admits the
   // epilogue's `nst` stores (a LOWER bound of what the epilogue issued: stores share the in-order vmcnt on gfx9).
-  constexpr bool XPF = PERSIST && MODE == GCD_GEMM_PLAIN && !SPLITK;
+  constexpr bool XPF = PERSIST && MODE == GCD_GEMM_PLAIN && !SPLITK && !(VAR & 8);
   int nst = 0;
 
   auto run_tiles = [&](auto GRP) {
@@ -419,7 +427,12 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
       }
       nst = 0;
       asm volatile("" : "+s"(wm_base), "+s"(wn_base), "+v"(elane));
-      if constexpr (SPLITK) {   // raw fp32 partial sums of this K slice
+      if constexpr ((VAR & 1) != 0) {   // ablation: K loop only
+#pragma unroll
+        for (int c = 0; c < 10; ++c)
+#pragma unroll
+          for (int tb = 0; tb < 4; ++tb) asm volatile("" ::"v"(acc[c][tb]));
+      } else if constexpr (SPLITK) {   // raw fp32 partial sums of this K slice
         GemmK q = p;
         q.out = (float*)p.out + (int64_t)e_kz * p.split_stride;
         gcd_epilogue_64x160(q, acc, wm_base, wn_base, elane);
@@ -440,13 +453,15 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
       } else {
         const bool full = wm_base + 64 <= p.M && wn_base + 160 <= p.N && e_bias_ok;
         const float* lb = e_bias + 160 * wn;
-        if (full && p.out_kind == GCD_OUT_GEGLU && (p.ldo & 7) == 0 && !p.out_blocked) {
+        constexpr bool E_GEGLU = EPI == 0 || EPI == 1, E_F16 = EPI == 0 || EPI == 2, E_F32 = EPI == 0 || EPI == 3,
+                       E_R2 = EPI == 0 || EPI == 4, E_R2H = EPI == 0 || EPI == 5;
+        if (E_GEGLU && full && p.out_kind == GCD_OUT_GEGLU && (p.ldo & 7) == 0 && !p.out_blocked) {
           gcd_epi_geglu_rows_full(p, acc, wm_base, wn_base, elane, lb, e_stage);
           nst = 10;
-        } else if (full && p.out_kind == GCD_OUT_F16 && !p.R1 && !p.R2 && !p.frame_alpha && (p.ldo & 7) == 0) {
+        } else if (E_F16 && full && p.out_kind == GCD_OUT_F16 && !p.R1 && !p.R2 && !p.frame_alpha && (p.ldo & 7) == 0) {
           gcd_epi_f16_rows_full(p, acc, wm_base, wn_base, elane, lb, e_stage);
           nst = 20;
-        } else if (full && e_alpha_uni && p.out_kind == GCD_OUT_F16 && p.R1 && p.R2 && (p.ldo & 3) == 0) {
+        } else if (E_R2H && full && e_alpha_uni && p.out_kind == GCD_OUT_F16 && p.R1 && p.R2 && (p.ldo & 3) == 0) {
           float sa = p.s_acc, sr1 = p.s_r1, sr2 = p.s_r2;
           if (p.frame_alpha) {
             const float al = p.frame_alpha[e_m0 / p.rows_per_alpha];
@@ -456,7 +471,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
           }
           gcd_epi_f32_rows_full<true, true, true>(p, acc, wm_base, wn_base, elane, lb, e_stage, sa, sr1, sr2);
           nst = 40;
-        } else if (full && e_alpha_uni && p.out_kind == GCD_OUT_F32) {
+        } else if ((E_F32 || E_R2) && full && e_alpha_uni && p.out_kind == GCD_OUT_F32 &&
+                   (p.R2 ? (E_R2 && (EPI == 0 || p.R1)) : E_F32)) {
           float sa = p.s_acc, sr1 = p.s_r1, sr2 = p.s_r2;
           if (p.frame_alpha) {
             const float al = p.frame_alpha[e_m0 / p.rows_per_alpha];
@@ -464,12 +480,17 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
             sr2 = al;
             if (p.r1_blend) sr1 *= 1.0f - al;
           }
-          if (p.R2) {
-            p.R1 ? gcd_epi_f32_rows_full<true, true>(p, acc, wm_base, wn_base, elane, lb, e_stage, sa, sr1, sr2)
-                 : gcd_epi_f32_rows_full<false, true>(p, acc, wm_base, wn_base, elane, lb, e_stage, sa, sr1, sr2);
-          } else {
-            p.R1 ? gcd_epi_f32_rows_full<true, false>(p, acc, wm_base, wn_base, elane, lb, e_stage, sa, sr1, sr2)
-                 : gcd_epi_f32_rows_full<false, false>(p, acc, wm_base, wn_base, elane, lb, e_stage, sa, sr1, sr2);
+          if constexpr (E_R2) {
+            if (p.R2) {
+              if (EPI != 0 || p.R1) gcd_epi_f32_rows_full<true, true>(p, acc, wm_base, wn_base, elane, lb, e_stage, sa, sr1, sr2);
+              else gcd_epi_f32_rows_full<false, true>(p, acc, wm_base, wn_base, elane, lb, e_stage, sa, sr1, sr2);
+            }
+          }
+          if constexpr (E_F32) {
+            if (!p.R2) {
+              p.R1 ? gcd_epi_f32_rows_full<true, false>(p, acc, wm_base, wn_base, elane, lb, e_stage, sa, sr1, sr2)
+                   : gcd_epi_f32_rows_full<false, false>(p, acc, wm_base, wn_base, elane, lb, e_stage, sa, sr1, sr2);
+            }
           }
           nst = 40;
         } else {
@@ -477,7 +498,14 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
         }
       }
       if (!XPF) nst = 0;   // without the prefetch every DMA piece of the next tile is younger than the stores
-      if (PERSIST) __syncthreads();   // epilogue LDS use vs the next tile's K-tile 1 pieces (buffer 1)
+      if (PERSIST) {   // epilogue LDS use vs the next tile's K-tile 1 pieces (buffer 1)
+        if constexpr ((VAR & 4) != 0) {
+          P8_LGKM0();
+          P8_BAR();
+        } else {
+          __syncthreads();
+        }
+      }
     }   // tile loop
   };
   if (grp == 0) run_tiles(std::integral_constant<int, 0>{});
@@ -501,10 +529,10 @@ void p8_extents(GemmK& kk) {
   kk.w_bytes = (uint32_t)((int64_t)kk.N * kk.K * 2);
 }
 
-template <int MODE, int VAR = 0>
+template <int MODE, int VAR = 0, int EPI = 0>
 int launch_p8(const GemmK& k, hipStream_t s) {
   static GcdPerDeviceOnce attr_once;
-  auto fn = gemm_p8_kernel<MODE, VAR>;
+  auto fn = gemm_p8_kernel<MODE, VAR, EPI>;
   GCD_CHECK_HIP(attr_once.opt_in((const void*)fn, P8_SMEM_LAUNCH));
   GemmK kk = k;
   p8_extents<MODE>(kk);
@@ -564,6 +592,28 @@ bool gcd_gemm_p8_supported(const GemmK& k, int mode) {
 }
 
 int gcd_gemm_p8_launch(const GemmK& k, int mode, bool persist, hipStream_t s) {
+#ifdef GCD_ABLATION_BUILD
+  {   // GCD_TUNE_GEMM_IMPL = 64 + ablation bits (PLAIN, persistent grids only)
+    const int var = gcd_tune_get(GCD_TUNE_GEMM_IMPL) - 64;
+    if (var > 0 && var < 16 && mode == GCD_GEMM_PLAIN && persist && !k.colstats) {
+      const int epi = k.out_kind == GCD_OUT_GEGLU ? 1 : (k.out_kind == GCD_OUT_F16 && !k.R1 && !k.R2 && !k.frame_alpha) ? 2 : 3;
+      if (k.R2) return -1 + 0 * gcd_tune_get(0);   // (no ablation instantiations of the two-residual path)
+#define P8_ABL(V)                                                             \
+  case V:                                                                     \
+    return epi == 1   ? launch_p8<GCD_GEMM_PLAIN, 2048 + V, 1>(k, s)          \
+           : epi == 2 ? launch_p8<GCD_GEMM_PLAIN, 2048 + V, 2>(k, s)          \
+                      : launch_p8<GCD_GEMM_PLAIN, 2048 + V, 3>(k, s);
+      switch (var) {
+        P8_ABL(1)
+        P8_ABL(2)
+        P8_ABL(4)
+        P8_ABL(8)
+        default: break;
+      }
+#undef P8_ABL
+    }
+  }
+#endif
   if (k.colstats) {
     switch (mode) {
       case GCD_GEMM_PLAIN:
@@ -576,11 +626,25 @@ int gcd_gemm_p8_launch(const GemmK& k, int mode, bool persist, hipStream_t s) {
   }
   switch (mode) {
     case GCD_GEMM_PLAIN:
-      return persist ? launch_p8<GCD_GEMM_PLAIN, 2048>(k, s) : launch_p8<GCD_GEMM_PLAIN>(k, s);
+      // one epilogue fast path per PLAIN instantiation (EPI), chosen from the descriptor
+      if (k.out_kind == GCD_OUT_GEGLU)
+        return persist ? launch_p8<GCD_GEMM_PLAIN, 2048, 1>(k, s) : launch_p8<GCD_GEMM_PLAIN, 0, 1>(k, s);
+      if (k.out_kind == GCD_OUT_F16 && !k.R1 && !k.R2 && !k.frame_alpha)
+        return persist ? launch_p8<GCD_GEMM_PLAIN, 2048, 2>(k, s) : launch_p8<GCD_GEMM_PLAIN, 0, 2>(k, s);
+      if (k.out_kind == GCD_OUT_F16)
+        return persist ? launch_p8<GCD_GEMM_PLAIN, 2048, 5>(k, s) : launch_p8<GCD_GEMM_PLAIN, 0, 5>(k, s);
+      if (k.R2) return persist ? launch_p8<GCD_GEMM_PLAIN, 2048, 4>(k, s) : launch_p8<GCD_GEMM_PLAIN, 0, 4>(k, s);
+      return persist ? launch_p8<GCD_GEMM_PLAIN, 2048, 3>(k, s) : launch_p8<GCD_GEMM_PLAIN, 0, 3>(k, s);
     case GCD_GEMM_CONV3X3:
-      return persist ? launch_p8<GCD_GEMM_CONV3X3, 2048>(k, s) : launch_p8<GCD_GEMM_CONV3X3>(k, s);
+      if (k.out_kind != GCD_OUT_F32)   // fp16 / GEGLU outputs of a convolution: the all-paths instantiation
+        return persist ? launch_p8<GCD_GEMM_CONV3X3, 2048>(k, s) : launch_p8<GCD_GEMM_CONV3X3>(k, s);
+      if (k.R2) return persist ? launch_p8<GCD_GEMM_CONV3X3, 2048, 4>(k, s) : launch_p8<GCD_GEMM_CONV3X3, 0, 4>(k, s);
+      return persist ? launch_p8<GCD_GEMM_CONV3X3, 2048, 3>(k, s) : launch_p8<GCD_GEMM_CONV3X3, 0, 3>(k, s);
     default:
-      return persist ? launch_p8<GCD_GEMM_TEMPORAL3, 2048>(k, s) : launch_p8<GCD_GEMM_TEMPORAL3>(k, s);
+      if (k.out_kind != GCD_OUT_F32)
+        return persist ? launch_p8<GCD_GEMM_TEMPORAL3, 2048>(k, s) : launch_p8<GCD_GEMM_TEMPORAL3>(k, s);
+      if (k.R2) return persist ? launch_p8<GCD_GEMM_TEMPORAL3, 2048, 4>(k, s) : launch_p8<GCD_GEMM_TEMPORAL3, 0, 4>(k, s);
+      return persist ? launch_p8<GCD_GEMM_TEMPORAL3, 2048, 3>(k, s) : launch_p8<GCD_GEMM_TEMPORAL3, 0, 3>(k, s);
   }
 }
 

@@ -258,13 +258,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
   int64_t nrows = rows_per_inst - r0;
   if (nrows > rows_per_chunk) nrows = rows_per_chunk;
   const int64_t base = (int64_t)inst * rows_per_inst + r0;
-  const int64_t total = nrows * cv4;
-  auto src_of = [&](int64_t idx, int64_t& r, int& c) -> const float* {
-    r = idx / cv4;
-    c = (int)(idx - r * cv4) * 4;
-    return (c < C1) ? x1 + (base + r) * ld1 + c : x2 + (base + r) * ld2 + (c - C1);
+  const int total = (int)(nrows * cv4);        // a chunk is ~16 K elements: 32-bit indices
+  // Flat index idx = r * cv4 + c4 walks the chunk with stride 256: (r, c4) advance by (256 / cv4, 256 % cv4) with one
+  // carry — no division in the loop (round 4: the 64-bit idx / cv4 per vector cost more VALU than the normalisation).
+  int r = t / cv4, c4 = t - r * cv4;
+  const int qs = 256 / cv4, rs = 256 - qs * cv4;
+  auto src_of = [&](int rr, int c) -> const float* {
+    return (c < C1) ? x1 + (base + rr) * ld1 + c : x2 + (base + rr) * ld2 + (c - C1);
   };
-  auto emit = [&](const f32x4 v, int64_t r, int c) {
+  auto emit = [&](const f32x4 v, int rr, int c) {
     const f32x4 a = *(const f32x4*)(sc + c), b = *(const f32x4*)(sh + c);
     f16x4 o;
 #pragma unroll
@@ -273,28 +275,43 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
       if (silu) u = silu_f(u);
       o[e] = (f16)u;
     }
-    *(f16x4*)(y + (base + r) * ldy + c) = o;
+    *(f16x4*)(y + (base + rr) * ldy + c) = o;
     if (raw) {
       f16x4 q;
 #pragma unroll
       for (int e = 0; e < 4; ++e) q[e] = (f16)v[e];
-      *(f16x4*)(raw + (base + r) * ldraw + c) = q;
+      *(f16x4*)(raw + (base + rr) * ldraw + c) = q;
     }
   };
-  int64_t idx = t;
-  for (; idx + 256 < total; idx += 512) {
-    int64_t ra, rb;
-    int ca, cb;
-    const f32x4 va = *(const f32x4*)src_of(idx, ra, ca);
-    const f32x4 vb = *(const f32x4*)src_of(idx + 256, rb, cb);
-    emit(va, ra, ca);
-    emit(vb, rb, cb);
+  // four vectors (64 B) in flight per thread
+  int idx = t;
+  for (; idx + 768 < total; idx += 1024) {
+    int rr[4], cc[4];
+    f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      rr[k] = r;
+      cc[k] = c4 * 4;
+      v[k] = *(const f32x4*)src_of(r, c4 * 4);
+      r += qs;
+      c4 += rs;
+      if (c4 >= cv4) {
+        c4 -= cv4;
+        ++r;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) emit(v[k], rr[k], cc[k]);
   }
-  if (idx < total) {
-    int64_t ra;
-    int ca;
-    const f32x4 va = *(const f32x4*)src_of(idx, ra, ca);
-    emit(va, ra, ca);
+  for (; idx < total; idx += 256) {
+    const f32x4 v = *(const f32x4*)src_of(r, c4 * 4);
+    emit(v, r, c4 * 4);
+    r += qs;
+    c4 += rs;
+    if (c4 >= cv4) {
+      c4 -= cv4;
+      ++r;
+    }
   }
 }
 

@@ -331,7 +331,7 @@ def test_feedforward_tile_blocked_hidden(gpu, gemm_impl):
     b2 = torch.randn(C, generator=g).to(gpu)
     r1 = torch.randn(M, C, generator=g).to(gpu)
     ok = ops.gemm_hidden_blocked_ok(M, 2 * H, C, enabled=True)
-    assert ok == {0: False, 2: True, 6: False}[gemm_impl]     # 50 FF-out tiles < 192: automatic says no
+    assert ok == {0: False, 2: True, 3: True, 6: False}[gemm_impl]     # 50 FF-out tiles < 192: automatic says no
     hid = torch.empty(M, H, dtype=torch.float16, device=gpu)
     out = torch.empty(M, C, device=gpu)
     ops.gemm(x, w1, hid, M=M, bias=b1, out_kind=ops.OUT_GEGLU)
@@ -548,7 +548,7 @@ def test_gemm_column_sums_for_groupnorm(gpu, gemm_impl, case):
     out = torch.empty(M, N, device=gpu)
     ok = ops.gemm(A, Wp, out, probe_colstats=True, **kw)
     # automatic choice: only grids of >= 192 tiles go to the ping-pong kernel; tile64 forces the other one
-    expect = {0: case == "plain_r1_persistent", 2: True, 6: False}[gemm_impl]
+    expect = {0: case == "plain_r1_persistent", 2: True, 3: True, 6: False}[gemm_impl]
     assert ok == expect, f"colstats support: got {ok}, expected {expect}"
     cs = torch.full((2 * (M // 64), N), float("nan"), device=gpu)
     if not ok:
