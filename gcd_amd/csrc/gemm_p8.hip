@@ -67,8 +67,8 @@ constexpr int P8_GROUP_M = 4;
 // VAR bits: 2048 persistent (256 workgroups walk the tiles), 4096 per-64-row column statistics (gcd_gemm_desc.colstats),
 // 16384 split-K (raw fp32 partial sums of K slice L % splitk).
 // Ablation bits (GCD_ABLATION_BUILD only, tools/gemm_bench_ablate; wrong results by design except 4 and 8):
-//   1 no epilogue   2 no K loop (epilogue of zeros)   4 LDS-only barrier at the end of a tile (stores and the
-//   prefetched K-tile stay in flight)   8 no cross-tile prefetch
+//   1 no epilogue   2 no K loop (epilogue of zeros)   4 __syncthreads() (vmcnt(0) drain) at the end of a tile instead of
+//   the LDS-only barrier   8 no cross-tile prefetch
 // EPI: which full-tile fast path of the epilogue this instantiation carries (the generic direct path is always there,
 // for ragged tiles): 0 all of them (run-time choice per tile), 1 GEGLU, 2 fp16 rows without residuals, 3 fp32 rows
 // with at most the first residual, 4 fp32 rows with both residuals (AlphaBlender), 5 fp16 rows with both residuals.  One path per kernel keeps the tile boundary free of register spills (whose reloads
@@ -498,12 +498,16 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
         }
       }
       if (!XPF) nst = 0;   // without the prefetch every DMA piece of the next tile is younger than the stores
-      if (PERSIST) {   // epilogue LDS use vs the next tile's K-tile 1 pieces (buffer 1)
+      if (PERSIST) {
+        // The epilogue's LDS staging reads are retired (lgkmcnt) before the next tile's K-tile 1 pieces land in buffer 1;
+        // its global STORES and the prefetched K-tile stay in flight across this barrier — __syncthreads() would wait
+        // vmcnt(0) here (an LDS-DMA is pending) and drain both (measured: L0 GEGLU 665 -> 597 us, L1 431 -> 410,
+        // profiles/r04e_p8_ablations.txt).  VAR bit 4 keeps the draining form for the A/B.
         if constexpr ((VAR & 4) != 0) {
+          __syncthreads();
+        } else {
           P8_LGKM0();
           P8_BAR();
-        } else {
-          __syncthreads();
         }
       }
     }   // tile loop
