@@ -18,7 +18,7 @@ PKG = CSRC.parent
 ROOT = PKG.parent
 LIB = PKG / "libgcd_amd.so"
 STAMP = PKG / ".libgcd_amd.stamp"
-SOURCES = ["runtime.hip", "gemm.hip", "gemm_pp.hip", "gemm_p8.hip", "norm.hip", "attention.hip", "attn_bwd.hip",
+SOURCES = ["runtime.hip", "gemm.hip", "gemm_pp.hip", "gemm_p8.hip", "gemm_p8x.hip", "norm.hip", "attention.hip", "attn_bwd.hip",
            "elementwise.hip", "backward.hip"]
 HEADERS = [CSRC / "common.h", CSRC / "gemm_common.h", ROOT / "include" / "gcd_amd.h"]
 ARCH = "gfx950"

@@ -516,9 +516,10 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
       gcd_gemm_pp_supported(k, d->mode) && d->N >= 160 && d->N % 4 == 0) {
     const int64_t tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 319) / 320);
     int splitk = (int)(256 / tiles);
-    if (tiles <= 32) {
+    if (tiles <= 32 && d->K >= 4096) {
       // a handful of tiles and a very long K: the weight gradients of the fine-tune step (dW = dY^T X, the
-      // contraction runs over the tokens).  Up to 32 K slices of at least 640, as many as the scratch holds.
+      // contraction runs over the tokens: K >= 43 008).  Up to 32 K slices of at least 640, as many as the scratch
+      // holds.  (K >= 4096 keeps the inference path's tiny-M Linears — K = 320 .. 1280 — on their round-2 kernels.)
       if (splitk > 32) splitk = 32;
       while (splitk > 1 && (d->K / splitk < 640 || d->workspace_bytes < (int64_t)splitk * d->M * d->N * 4)) --splitk;
       if (splitk >= 2 && ((uintptr_t)d->workspace & 15) == 0)

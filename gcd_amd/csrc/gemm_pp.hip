@@ -589,6 +589,9 @@ int launch_pp_splitk(const GemmK& k, int splitk, float* ws, hipStream_t s) {
 bool gcd_gemm_p8_supported(const GemmK& k, int mode);
 int gcd_gemm_p8_launch(const GemmK& k, int mode, bool persist, hipStream_t s);
 int gcd_gemm_p8_launch_splitk(const GemmK& k, int mode, int splitk, float* ws, hipStream_t s);
+// gemm_p8x.hip: 256 x 160 tiles, the fp16-output epilogues interleaved into the next tile's K loop
+bool gcd_gemm_p8x_supported(const GemmK& k, int mode);
+int gcd_gemm_p8x_launch(const GemmK& k, hipStream_t s);
 
 int gcd_gemm_pp_launch_splitk(const GemmK& k, int mode, int splitk, float* ws, hipStream_t s) {
   if (gcd_tune_get(GCD_TUNE_GEMM_IMPL) != 3 && gcd_gemm_p8_supported(k, mode)) {
@@ -655,8 +658,13 @@ int gcd_gemm_pp_launch(const GemmK& k, int mode, hipStream_t s) {
   // teardown, 6-7 % on the K = 320 / 640 shapes); otherwise one workgroup per tile.
   const int64_t tiles = (int64_t)((k.M + PP_BM - 1) / PP_BM) * ((k.N + PP_BN - 1) / PP_BN);
   const bool persist = tiles > 256 && gcd_tune_get(GCD_TUNE_GEMM_IMPL) != 4;   // knob 4: never persistent
-  // the 8-phase K loop (gemm_p8.hip) wherever it applies; knob 3 keeps this file's 32-deep ring kernel
-  if (gcd_tune_get(GCD_TUNE_GEMM_IMPL) != 3 && gcd_gemm_p8_supported(k, mode))
+  // the 8-phase K loop (gemm_p8.hip) wherever it applies; knob 3 keeps this file's 32-deep ring kernel.
+  // Knob 10 (only): the GEGLU / q|k|v projections of the large grids on gemm_p8x.hip, the epilogue-under-the-next-
+  // K-loop kernel — correct, and 15-35 % SLOWER than gemm_p8 (profiles/r04g_p8x_ab.txt: its 256 x 160 tiles stage
+  // 48 % more operand bytes per FLOP through the vector-memory -> LDS path), so it is not part of the automatic choice.
+  const int impl_knob = gcd_tune_get(GCD_TUNE_GEMM_IMPL);
+  if (impl_knob == 10 && gcd_gemm_p8x_supported(k, mode)) return gcd_gemm_p8x_launch(k, s);
+  if (impl_knob != 3 && gcd_gemm_p8_supported(k, mode))
     return gcd_gemm_p8_launch(k, mode, persist, s);
   if (k.ln_out) {   // validated by gcd_gemm_f16: PLAIN mode, N == 320
     if (mode != GCD_GEMM_PLAIN) {
