@@ -14,7 +14,7 @@ the timed region.  Weights are random-init tensors of the Kubric architecture (t
 tensors re-drawn so the network is not identically 0), inputs synthetic and resident in HBM.
 
 Prints ONE JSON line on rank 0 (see the driver contract), including
-  roofline      dominant kernel family (gemm_pp_kernel / gemm_f16_kernel, the MFMA implicit GEMMs): algorithmic
+  roofline      dominant kernel family (gemm_p8_kernel / gemm_pp_kernel / gemm_f16_kernel, the MFMA implicit GEMMs): algorithmic
                 FLOPs of all its launches in one step / the sum of their durations, measured with
                 HIP events on the launch stream in an instrumented eager step right after the timed
                 region (the timed region itself replays a hipGraph, which has no per-kernel hooks);
@@ -401,7 +401,7 @@ def main():
                          "unit": "TFLOP/s", "frac": round(gemm_tflops / PEAK_MFMA_TFLOPS, 4),
                          "traffic": traffic, "traffic_unit": "bytes per launch (fabric-side: HBM + Infinity Cache)",
                          "traffic_profile": traffic_note, "sources_digest": sources_digest(),
-                         "kernel": "gemm_pp_kernel + gemm_f16_kernel (MFMA implicit-GEMM family: Linear, Conv2d 3x3/1x1, Conv3d (3,1,1))",
+                         "kernel": "gemm_p8_kernel (+ gemm_pp_kernel, gemm_f16_kernel for the shapes it does not take; MFMA implicit-GEMM family: Linear, Conv2d 3x3/1x1, Conv3d (3,1,1))",
                          "launches_per_step": gk["launches"],
                          "algorithmic_tflop_per_step": round(gk["flops"] / 1e12, 3),
                          "kernel_ms_per_step": round(gk["ms"], 3)},

@@ -38,3 +38,7 @@ python tools/rocpd_stats.py $(find $OUT/trace_train -name "*_results.db" | head 
 rm -rf $OUT/trace $OUT/trace_train $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_TCC_HIT_sum $OUT/pmc_sq $OUT/pmc_sq2
 du -sh $ROOT/gpurun_out
 ls -la $OUT
+# round 4: the CPU path timed at the metric's own shape beside the GPU number (one oracle step at 14x72x128, minutes)
+if [ "${GCD_CPU_FULL:-0}" = "1" ]; then
+  python bench.py --steps 10 --warmup 2 --repeats 1 --cpu-baseline-full > $OUT/bench_cpu_full.json 2> $OUT/bench_cpu_full.err
+fi

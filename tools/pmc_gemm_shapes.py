@@ -22,7 +22,7 @@ import sys
 from collections import OrderedDict, defaultdict
 
 csv.field_size_limit(1 << 30)
-GEMM_KEYS = ("gemm_pp_kernel", "gemm_f16_kernel", "splitk_reduce_kernel")
+GEMM_KEYS = ("gemm_p8_kernel", "gemm_p8x_kernel", "gemm_pp_kernel", "gemm_f16_kernel", "splitk_reduce_kernel")
 
 
 def dispatches(path):

@@ -23,7 +23,7 @@ from collections import defaultdict
 csv.field_size_limit(1 << 30)
 
 FAMILIES = [
-    ("gemm", ("gemm_pp_kernel", "gemm_f16_kernel", "splitk_reduce_kernel")),
+    ("gemm", ("gemm_p8_kernel", "gemm_p8x_kernel", "gemm_pp_kernel", "gemm_f16_kernel", "splitk_reduce_kernel")),
     ("attn_spatial", ("attn_spatial",)),
     ("attn_temporal", ("attn_temporal",)),
     ("groupnorm", ("gn_stats", "gn_apply")),
