@@ -125,8 +125,10 @@ _WS = {}
 
 def _train_ws(device) -> torch.Tensor:
     """Split-K scratch of the fine-tune step: the weight gradients are few-tile GEMMs whose contraction runs
-    over all tokens (gcd_gemm_f16 splits K up to 32 ways when the scratch holds the partial sums), 384 MB."""
-    key = torch.device(device).index or 0
+    over all tokens (gcd_gemm_f16 splits K up to 32 ways when the scratch holds the partial sums), 384 MB.
+    One per (device, stream), like ops._splitk_ws: the partial sums of a launch live there until its reduce kernel
+    has run, so two streams must not share it."""
+    key = (torch.device(device).index or 0, ops._stream())
     w = _WS.get(key)
     if w is None:
         w = torch.empty(96 << 20, dtype=_f32, device=device)
