@@ -228,6 +228,15 @@ class EDMSampler(BaseDiffusionSampler):
             self.last_path = "fused"
             return self._call_fused(denoiser, x, cond, default(uc, cond), num_steps)
         self.last_path = "generic"
+        if not EulerEDMSampler._warned_generic and getattr(x, "is_cuda", False):
+            # said ONCE per process: the generic path is correct but launches every step from Python (no hipGraph,
+            # no fused guidance / Euler update) — a closure that upstream edited no longer matches fused_from_closure
+            EulerEDMSampler._warned_generic = True
+            import warnings
+            warnings.warn("gcd_amd.sampling.EulerEDMSampler: the denoiser callable was not recognised as the "
+                          "DiffusionEngine.sample_video closure (diffusion.py:526-532) or a FusedDenoiser; running "
+                          "the generic per-step path instead of the fused hipGraph loop (see INTEGRATION.md §1)",
+                          RuntimeWarning, stacklevel=2)
         x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
         sig_host = sigmas.detach().cpu().tolist() if self.s_churn > 0 else None
         for i in range(num_sigmas - 1):
@@ -366,6 +375,7 @@ class FusedEulerLoop:
 
 class EulerEDMSampler(EDMSampler):
     """Deterministic Euler steps, no correction (sampling.py:225-230)."""
+    _warned_generic = False    # the generic-path notice is given once per process
 
     def possible_correction_step(self, euler_step, x, d, dt, next_sigma, denoiser, cond, uc):
         return euler_step
