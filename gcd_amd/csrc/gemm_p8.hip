@@ -54,6 +54,14 @@ constexpr int P8_BIAS0 = P8_STAGE0 + 8 * GCD_EPI_STAGE_BYTES;    // 159744
 static_assert(P8_BIAS0 >= P8_SMEM, "staging must cover the tail of buffer 1");
 constexpr int P8_SMEM_LAUNCH = P8_BIAS0 + 2 * 320 * 4;           // 162304 of the 163840 B of LDS
 constexpr int P8_GROUP_M = 4;
+// MODE 3 (internal, chosen by gcd_gemm_p8_launch for stride-1 3x3 convolutions whose rows are 64-token aligned):
+// CONV3X3 with a HALO A panel.  K order (kh, cin-chunk, kw): one staged panel — the tile's image-row segments, each with
+// one halo pixel on either side, padded to a multiple of 8 rows — serves the three kw K-tiles, whose fragments are read at
+// row offsets 0 / 1 / 2: the A side of the LDS-DMA (and of the L2 -> LDS traffic) drops by 3.
+constexpr int P8_CONV_HALO = 3;
+constexpr int P8_PANEL = 288 * 128;                      // 36864: largest panel (four 64-pixel segments of 72 rows)
+constexpr int P8_HALO_W0 = 2 * P8_PANEL;                 // 73728: the two W K-tile buffers follow the two panels
+static_assert(P8_HALO_W0 + 2 * P8_W_BYTES <= P8_BIAS0, "halo layout must fit below the addend buffers");
 
 #define P8_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define P8_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -109,7 +117,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
   // PLAIN: the four rows differ by wave-uniform multiples of lda: one per-lane offset (r = 0) + scalar deltas.
   // conv modes: a per-row offset of the current tap (OOB when the tap leaves the image / clip), re-derived from the
   // packed output coordinates when the K walk crosses a tap.
-  unsigned a_off[4] = {0, 0, 0, 0};
+  constexpr bool HALO = MODE == P8_CONV_HALO;
+  unsigned a_off[4] = {0, 0, 0, 0};   // (HALO: panel pieces 0-3 of this wave, for the kh of the panel being staged)
   unsigned a_pk[4] = {0, 0, 0, 0};    // TEMPORAL3: frame-in-clip << 26 | token
   int a_tap[2] = {0, 0}, a_c0[2] = {0, 0};     // K position of the next stage of each region (conv modes), block-uniform
   const unsigned a_d8 = (unsigned)(8 * p.lda * 2), a_d32 = (unsigned)(32 * p.lda * 2);
@@ -126,7 +135,36 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
   // image row, so (frame, y, x0) of a piece is wave-uniform — one packed SGPR per piece, frame << 21 | y << 11 | x0,
   // derived once per tile; at a tap change the row part of the address is scalar arithmetic and a lane only adds its
   // own x (lane >> 3) and range-checks it.
-  unsigned a_pc[4] = {0, 0, 0, 0};
+  unsigned a_pc[5] = {0, 0, 0, 0, 0};
+  // HALO geometry: segments of w = min(Wo, 256) pixels, ws = w + 8 panel rows each; piece q = wave + 8 j
+  const int h_w = HALO ? min(p.Wo, 256) : 0, h_ws = h_w + 8;
+  const int h_npieces = HALO ? (256 / max(h_w, 1)) * h_ws / 8 : 0;
+  const int h_nck = HALO ? p.Cin >> 6 : 1;                 // 64-channel chunks per tap
+  const bool h_has5 = wave + 32 < h_npieces;
+  int h_kh = 0, h_ck = 0;                                  // (kh, chunk) of the NEXT panel to stage
+  int h_wkh = 0, h_wck = 0, h_wkw = 0;                     // (kh, chunk, kw) of the next W K-tile to stage
+  // (the lane id is made opaque wherever a loop-invariant per-lane value would otherwise be hoisted out of the K loop
+  //  and then SPILLED: a reload waits vmcnt(0) and drains the DMA pipeline)
+  auto lane_now = [&]() -> unsigned {
+    unsigned ln = __lane_id();
+    asm volatile("" : "+v"(ln));
+    return ln;
+  };
+  auto halo_piece_off = [&](int j, int kh) -> unsigned {   // per-lane offset of panel piece j for tap row kh
+    const unsigned ln = lane_now();
+    const unsigned sc = ((ln & 7) ^ (ln >> 3)) << 4;
+    const unsigned lda2 = (unsigned)(p.lda * 2);
+    const unsigned pc = a_pc[j];
+    const int x0p1 = pc & 2047, y = (pc >> 11) & 1023, fr = (int)(pc >> 21);
+    const int iy = y + kh - 1, ix = x0p1 - 1 + (int)(ln >> 3);
+    const bool row_ok = iy >= 0 && iy < p.Hi && fr < p.a_frames;
+    const unsigned rowbase = (unsigned)((fr * p.Hi + iy) * p.Wi) * lda2;
+    return (row_ok && (unsigned)ix < (unsigned)p.Wi) ? rowbase + (unsigned)ix * lda2 + sc : OOB;
+  };
+  auto halo_set_kh = [&](int kh) {   // pieces 0-3 keep their offsets in registers; the 5th (1-4 waves) is derived when staged
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a_off[j] = halo_piece_off(j, kh);
+  };
   auto unpack_set = [&](int r, int tap) {
     if (MODE == GCD_GEMM_CONV3X3) {
       const unsigned pc = a_pc[r];
@@ -193,6 +231,22 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
       const int g = 2 * wave;
       const int m = m0 + 64 * (g >> 2) + 8 * (g & 3) + lrow;
       a_off[0] = (unsigned)m * (unsigned)(p.lda * 2) + srcchunk;    // rows >= M land past the extent: zeros
+    } else if (HALO) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int L0r = 8 * (wave + 8 * j);                 // first panel row of the piece
+        const int seg = L0r / h_ws, i0 = L0r - seg * h_ws;  // segment, row within it (row i <-> pixel x = i - 1)
+        const int ms = m0 + seg * h_w;                      // first output token of the segment
+        const int hw = p.Ho * p.Wo;
+        const int fr = ms / hw;
+        const int rem = ms - fr * hw;
+        const int y = rem / p.Wo;
+        a_pc[j] = __builtin_amdgcn_readfirstlane(
+            (int)(((unsigned)fr << 21) | ((unsigned)y << 11) | (unsigned)(rem - y * p.Wo + i0)));   // x0 + 1
+      }
+      h_kh = h_ck = 0;
+      h_wkh = h_wck = h_wkw = 0;
+      halo_set_kh(0);
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -281,11 +335,52 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
     }
   };
 
+  // HALO: one piece (j) of the next panel (index pn, buffer pn & 1); the panel counters advance with piece 3
+  auto halo_stage_piece = [&](int pn, int npanels, int j) {
+    if (pn < npanels && wave + 8 * j < h_npieces)
+      bload(rsrcA, j < 4 ? a_off[j < 4 ? j : 0] : halo_piece_off(4, h_kh), h_ck * 128,
+            smem + (pn & 1) * P8_PANEL + (wave + 8 * j) * 1024);
+  };
+  auto halo_next_panel = [&](int pn, int npanels) {   // before the first piece of panel pn: its kh's offsets
+    if (pn < npanels && pn > 0) {
+      if (++h_ck == h_nck) {
+        h_ck = 0;
+        ++h_kh;
+        halo_set_kh(h_kh);
+      }
+    }
+  };
+  auto halo_stage_W = [&](int kt, int nkt, int reg, auto CNT) {
+    constexpr int cnt = decltype(CNT)::value;
+    if (kt < nkt) {
+      const int ko = ((h_wkh * 3 + h_wkw) * p.Cin + h_wck * 64) * 2;
+      char* dst = smem + P8_HALO_W0 + (kt & 1) * P8_W_BYTES;
+#pragma unroll
+      for (int j = 0; j < cnt; ++j) bload(rsrcW, w_lane + w_roff[reg][j], ko, dst + w_row[reg][j] * 128);
+      if (reg == 1) {            // both regions of this K-tile are out: the W cursor moves on
+        if (++h_wkw == 3) {
+          h_wkw = 0;
+          if (++h_wck == h_nck) {
+            h_wck = 0;
+            ++h_wkh;
+          }
+        }
+      }
+    }
+  };
+
   // ---- fragment read addresses (per lane, within a buffer): row (lane & 15) of a 16-row block, logical chunk
   //      ks * 4 + (lane >> 4), physical slot = chunk ^ (row & 7) ----
   //      (k-step 1 = the same address with bit 6 flipped: chunk 4 + q = chunk q ^ 4)
   const int rdA0 = (64 * wm + (lane & 15)) * 128 + (((lane >> 4) ^ (lane & 7)) << 4);
-  const int rdW0 = P8_A_BYTES + (160 * wn + (lane & 15)) * 128 + (((lane >> 4) ^ (lane & 7)) << 4);
+  const int rdW0 = (HALO ? 0 : P8_A_BYTES) + (160 * wn + (lane & 15)) * 128 + (((lane >> 4) ^ (lane & 7)) << 4);
+  // HALO: token (seg, x) of tap kw sits in panel row seg * ws + x + kw; the wave's 64 tokens are 64 consecutive x.
+  // One base register; the kw-dependent row / slot part is re-derived per read (5 VALU, kw is a compile-time constant)
+  int rdAh0 = 0;
+  if (HALO) {
+    const int seg_w = (64 * wm) / h_w;
+    rdAh0 = (seg_w * h_ws + (64 * wm - seg_w * h_w) + (lane & 15)) * 128;
+  }
 
   // Cross-tile prefetch (persistent PLAIN kernels, as gemm_pp.hip): the NEXT tile's set_tile + K-tile 0 are issued
   // BEFORE the epilogue (buffer 0 is not staging space); the first counted wait of the next K loop admits the
@@ -313,11 +408,23 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
       prologue_a();
     }
     for (; L < L_end; L += L_step) {
-      if (!XPF) {
+      const int npanels = HALO ? nK / 3 : 0;     // (set below by set_tile for HALO: nK = 9 Cin / 64)
+      if constexpr (HALO) {
         set_tile(L);
-        prologue_a();
+#pragma unroll
+        for (int j = 0; j < 5; ++j) halo_stage_piece(0, nK / 3, j);    // panel 0, complete
+        halo_stage_W(0, nK, 0, C0{});
+        halo_stage_W(0, nK, 1, C1{});
+        halo_stage_W(1, nK, 0, C0{});
+        halo_stage_W(1, nK, 1, C1{});
+      } else {
+        if (!XPF) {
+          set_tile(L);
+          prologue_a();
+        }
+        prologue_b();
       }
-      prologue_b();
+      (void)npanels;
 
       GcdAcc16 acc;
 #pragma unroll
@@ -360,6 +467,86 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
       using I0 = std::integral_constant<int, 0>;
       using I1 = std::integral_constant<int, 1>;
 
+      if constexpr (HALO) {
+        const int np = nK / 3;
+        auto read_Ah = [&](const char* panel, int kw, int th) {
+          const unsigned ln = lane_now();
+          const int a0 = rdAh0 + kw * 128 + (int)(((ln >> 4) ^ ((ln + kw) & 7)) << 4);
+          const char* b0 = panel + a0 + th * 4096;
+          const char* b1 = panel + (a0 ^ 64) + th * 4096;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            af[i][0] = *(const f16x8*)(b0 + i * 2048);
+            af[i][1] = *(const f16x8*)(b1 + i * 2048);
+          }
+        };
+        // one K-tile (panel P, tap column KW): the four phases of the plain loop, A from the panel at row offset KW;
+        // W regions re-staged as there (RW0 in P2, RW1 in P4, K-tile t+2); in the KW = 0 K-tile the NEXT panel is staged,
+        // one piece per phase (piece 4 rides with piece 0): 8+ phases before its first read
+        auto ktile = [&](int P, auto KWT) {
+          constexpr int KW = decltype(KWT)::value;
+          const int kt = 3 * P + KW;
+          const char* panel = smem + (P & 1) * P8_PANEL;
+          const char* wbuf = smem + P8_HALO_W0 + (kt & 1) * P8_W_BYTES;
+          // P1 (th0, cp0)
+          if (KW == 0) {
+            halo_next_panel(P + 1, np);
+            halo_stage_piece(P + 1, np, 0);
+            halo_stage_piece(P + 1, np, 4);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          read_Ah(panel, KW, 0);
+          read_W(wbuf, 0);
+          P8_LGKM0();
+          P8_BAR();
+          mma(I0{}, I0{});
+          P8_BAR();
+          // P2 (th1, cp0)
+          if (KW == 0) halo_stage_piece(P + 1, np, 1);
+          halo_stage_W(kt + 2, nK, 0, C0{});
+          __builtin_amdgcn_sched_barrier(0);
+          read_Ah(panel, KW, 1);
+          P8_LGKM0();
+          P8_BAR();
+          mma(I1{}, I0{});
+          P8_BAR();
+          // P3 (th1, cp1)
+          if (KW == 0) halo_stage_piece(P + 1, np, 2);
+          __builtin_amdgcn_sched_barrier(0);
+          read_W(wbuf, 1);
+          P8_LGKM0();
+          P8_BAR();
+          mma(I1{}, I1{});
+          P8_BAR();
+          // P4 (th0, cp1)
+          if (KW == 0) halo_stage_piece(P + 1, np, 3);
+          halo_stage_W(kt + 2, nK, 1, C1{});
+          __builtin_amdgcn_sched_barrier(0);
+          read_Ah(panel, KW, 0);
+          // W K-tile kt+1 (and with it everything older, the next panel included) has landed; in flight stay the 5 W
+          // pieces of kt+2 and, in a KW = 0 K-tile, the 4-5 panel pieces just issued
+          if (kt + 2 >= nK) {
+            P8_VMCNT(0);
+          } else if (KW == 0 && P + 1 < np) {
+            if (h_has5) P8_VMCNT(10);
+            else P8_VMCNT(9);
+          } else {
+            P8_VMCNT(5);
+          }
+          P8_LGKM0();
+          P8_BAR();
+          mma(I0{}, I1{});
+          P8_BAR();
+        };
+        P8_VMCNT(5);   // panel 0 and W K-tile 0 have landed (the 5 pieces of W K-tile 1 may still fly)
+        P8_BAR();
+        if (G == 1) P8_BAR();
+        for (int P = 0; P < np; ++P) {
+          ktile(P, std::integral_constant<int, 0>{});
+          ktile(P, std::integral_constant<int, 1>{});
+          ktile(P, std::integral_constant<int, 2>{});
+        }
+      } else {
       // K-tile 0 has landed (the 7 pieces of prologue_b [+ nst epilogue stores] may still fly)
       if (nK > 1) {
         if (nst == 40) P8_VMCNT(47);
@@ -411,6 +598,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
         mma(I0{}, I1{});
         P8_BAR();
       }
+      }   // !HALO
       if (G == 0) P8_BAR();   // pairs with the stagger: every wave's reads of this tile are retired behind it
 
       // ---- epilogue (gemm_common.h) ----
@@ -522,7 +710,7 @@ template <int MODE>
 void p8_extents(GemmK& kk) {
   int64_t rows = kk.M, width = kk.K;
   kk.a_frames = 0;
-  if (MODE == GCD_GEMM_CONV3X3) {
+  if (MODE == GCD_GEMM_CONV3X3 || MODE == P8_CONV_HALO) {
     kk.a_frames = kk.M / (kk.Ho * kk.Wo);
     rows = (int64_t)kk.a_frames * kk.Hi * kk.Wi;
     width = kk.Cin;
@@ -595,6 +783,16 @@ bool gcd_gemm_p8_supported(const GemmK& k, int mode) {
   return true;
 }
 
+// Stride-1 3 x 3 convolutions that take the halo-panel K loop (MODE 3): whole 64-token wave spans inside one image row,
+// full tiles, fp32 output (the UNet's ResBlock / up-path convolutions at 72 x 128 and 36 x 64).  Knob 11: never.
+static bool p8_halo_ok(const GemmK& k, int mode) {
+  if (mode != GCD_GEMM_CONV3X3 || k.stride != 1 || k.up || k.asym || k.out_kind != GCD_OUT_F32) return false;
+  if (k.M % P8_BM != 0 || k.Wo % 64 != 0 || k.Wo > 2040) return false;
+  if (!(256 % k.Wo == 0 || k.Wo % 256 == 0)) return false;
+  if (k.Hi != k.Ho || k.Wi != k.Wo || k.K != 9 * k.Cin) return false;
+  return gcd_tune_get(GCD_TUNE_GEMM_IMPL) != 11;
+}
+
 int gcd_gemm_p8_launch(const GemmK& k, int mode, bool persist, hipStream_t s) {
 #ifdef GCD_ABLATION_BUILD
   {   // GCD_TUNE_GEMM_IMPL = 64 + ablation bits (PLAIN, persistent grids only)
@@ -618,6 +816,11 @@ int gcd_gemm_p8_launch(const GemmK& k, int mode, bool persist, hipStream_t s) {
     }
   }
 #endif
+  if (p8_halo_ok(k, mode)) {
+    if (k.colstats) return persist ? launch_p8<P8_CONV_HALO, 2048 + 4096>(k, s) : launch_p8<P8_CONV_HALO, 4096>(k, s);
+    if (k.R2) return persist ? launch_p8<P8_CONV_HALO, 2048, 4>(k, s) : launch_p8<P8_CONV_HALO, 0, 4>(k, s);
+    return persist ? launch_p8<P8_CONV_HALO, 2048, 3>(k, s) : launch_p8<P8_CONV_HALO, 0, 3>(k, s);
+  }
   if (k.colstats) {
     switch (mode) {
       case GCD_GEMM_PLAIN:

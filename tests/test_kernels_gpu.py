@@ -379,6 +379,56 @@ def test_conv3x3(gpu, frames, H, W, Cin, Cout, stride, up):
     assert e < TOL_F32, f"conv3x3 rel-L2 {e:.3e}"
 
 
+@pytest.mark.parametrize("frames,H,W,Cin,Cout,res", [
+    (2, 4, 64, 64, 320, 0),        # four 64-pixel row segments per 256-token tile
+    (3, 2, 128, 128, 320, 2),      # two 128-pixel segments; tiles start on odd / even image rows; both residuals
+    (2, 3, 128, 192, 640, 1),      # three chunks per tap; 384 tokens per frame: a frame boundary falls INSIDE a tile
+    (1, 2, 256, 64, 320, 1),       # one 256-pixel segment per tile
+    (1, 1, 512, 64, 320, 0)])      # segments of a longer image row: the right halo is a real neighbour pixel
+def test_conv3x3_halo_panel(gpu, gemm_impl, frames, H, W, Cin, Cout, res):
+    """The halo-panel K loop of gemm_p8.hip (stride-1 3x3 convolutions whose image rows are 64-token aligned: K order
+    (kh, cin-chunk, kw), one staged A panel with halo pixels serving the three kw taps): borders (zeros from the
+    out-of-range buffer offsets), frame boundaries inside a tile, residual epilogues, and the per-64-row column sums."""
+    from gcd_amd import ops, packing
+    g = _gen(55 + W)
+    x = _h(torch.randn(frames, Cin, H, W, generator=g))
+    w = _h(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    b = torch.randn(Cout, generator=g)
+    M = frames * H * W
+    assert M % 256 == 0
+    ref = F.conv2d(x, w, b, padding=1).permute(0, 2, 3, 1).reshape(M, Cout)
+    r1 = torch.randn(M, Cout, generator=g) if res >= 1 else None
+    r2 = torch.randn(M, Cout, generator=g) if res >= 2 else None
+    if r1 is not None:
+        ref = ref + r1
+    if r2 is not None:
+        ref = ref + 0.5 * r2
+    a = x.permute(0, 2, 3, 1).reshape(M, Cin).half().to(gpu)
+    out = torch.empty(M, Cout, device=gpu)
+    kw = dict(M=M, mode=ops.GEMM_CONV3X3, bias=b.to(gpu),
+              conv=dict(Cin=Cin, Hi=H, Wi=W, Ho=H, Wo=W, stride=1, upsample=0))
+    if r1 is not None:
+        kw.update(r1=r1.to(gpu))
+    if r2 is not None:
+        kw.update(r2=r2.to(gpu), s_r2=0.5)
+    ops.gemm(a, packing.pack_conv3x3(w).to(gpu), out, **kw)
+    torch.cuda.synchronize()
+    e = rel_l2(out, ref)
+    assert e < TOL_F32, f"halo conv3x3 {frames}x{H}x{W} Cin {Cin}: rel-L2 {e:.3e}"
+    # the same launch with GroupNorm column statistics (own kernel instantiation), where the shape allows them:
+    # rows 2k / 2k+1 of the buffer = sums / sums of squares over the 64 output rows of block k (_colsum_ref)
+    wp = packing.pack_conv3x3(w).to(gpu)
+    out2 = torch.empty(M, Cout, device=gpu)
+    if res <= 1 and ops.gemm(a, wp, out2, probe_colstats=True, **kw):
+        cs = torch.full((2 * (M // 64), Cout), float("nan"), device=gpu)
+        ops.gemm(a, wp, out2, colstats=cs, **kw)
+        torch.cuda.synchronize()
+        assert rel_l2(out2, ref) < TOL_F32
+        want = _colsum_ref(out2.cpu())
+        assert not torch.isnan(cs).any()
+        assert rel_l2(cs[0::2], want[0::2]) < 2e-6 and rel_l2(cs[1::2], want[1::2]) < 2e-6
+
+
 def test_conv3x3_padded_channels(gpu):
     """First conv (8 -> C, input channels zero-padded to 64) and last conv (C -> 4, N padded to 16)."""
     from gcd_amd import ops, packing
