@@ -76,7 +76,11 @@ static_assert(P8_HALO_W0 + 2 * P8_W_BYTES <= P8_BIAS0, "halo layout must fit bel
 // 16384 split-K (raw fp32 partial sums of K slice L % splitk).
 // Ablation bits (GCD_ABLATION_BUILD only, tools/gemm_bench_ablate; wrong results by design except 4 and 8):
 //   1 no epilogue   2 no K loop (epilogue of zeros)   4 __syncthreads() (vmcnt(0) drain) at the end of a tile instead of
-//   the LDS-only barrier   8 no cross-tile prefetch
+//   the LDS-only barrier   8 no cross-tile prefetch   16 / 32 / 64 flip the mode's default of: ds_reads before the
+//   LDS-DMA of a phase (PLAIN default; the conv modes stage first, for their tap arithmetic) / no s_setprio around the
+//   MFMA clusters (PLAIN default) / tile walk in groups of 8 instead of 4 M-tiles (PLAIN default).
+//   Measured (profiles/r04j_p8_variants.txt, two runs of 15): with all three L0 GEGLU 612-617 -> 500-509 us, L1 GEGLU
+//   400-403 -> 376-381, L2 GEGLU 337-346 -> 321-327; FF-out / proj / q|k|v within +-1 %.
 // EPI: which full-tile fast path of the epilogue this instantiation carries (the generic direct path is always there,
 // for ragged tiles): 0 all of them (run-time choice per tile), 1 GEGLU, 2 fp16 rows without residuals, 3 fp32 rows
 // with at most the first residual, 4 fp32 rows with both residuals (AlphaBlender), 5 fp16 rows with both residuals.  One path per kernel keeps the tile boundary free of register spills (whose reloads
@@ -92,6 +96,9 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
   constexpr bool PERSIST = (VAR & 2048) != 0;
   constexpr bool SPLITK = (VAR & 16384) != 0;
   constexpr bool STATS = (VAR & 4096) != 0;
+  constexpr bool READS_FIRST = (MODE == GCD_GEMM_PLAIN) != ((VAR & 16) != 0);
+  constexpr bool SETPRIO = (MODE != GCD_GEMM_PLAIN) != ((VAR & 32) != 0);
+  constexpr int GM = ((MODE == GCD_GEMM_PLAIN) != ((VAR & 64) != 0)) ? 8 : P8_GROUP_M;
 
   // ---- XCD-aware, panel-sharing tile assignment (bijective for any grid; as gemm_pp.hip) ----
   int L, L_end, L_step;
@@ -209,11 +216,11 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
     kz = SPLITK ? Lx % p.splitk : 0;
     {
       const int Lt = SPLITK ? Lx / p.splitk : Lx;
-      const int per_group = P8_GROUP_M * p.tiles_n;
+      const int per_group = GM * p.tiles_n;
       const int gi = Lt / per_group;
       const int rem = Lt - gi * per_group;
-      const int m_first = gi * P8_GROUP_M;
-      const int gm = min(P8_GROUP_M, p.tiles_m - m_first);
+      const int m_first = gi * GM;
+      const int gm = min(GM, p.tiles_m - m_first);
       tile_n = rem / gm;
       tile_m = m_first + rem - tile_n * gm;
     }
@@ -453,7 +460,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
       };
       auto mma = [&](auto TH, auto CP) {
         constexpr int th = decltype(TH)::value, cp = decltype(CP)::value;
-        __builtin_amdgcn_s_setprio(1);
+        if (SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -462,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
             for (int j = 0; j < 2; ++j)
               acc[5 * cp + i][2 * th + j] =
                   __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i][ks], af[j][ks], acc[5 * cp + i][2 * th + j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (SETPRIO) __builtin_amdgcn_s_setprio(0);
       };
       using I0 = std::integral_constant<int, 0>;
       using I1 = std::integral_constant<int, 1>;
@@ -563,34 +570,50 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
         const char* buf = smem + (kt & 1) * P8_BUF;
         // (each phase stages FIRST: the tap arithmetic of the conv modes then runs while no fragment is live)
         // P1 (th0, cp0)
-        stage_A(kt + 1, 0);
+        if (!READS_FIRST) stage_A(kt + 1, 0);
         __builtin_amdgcn_sched_barrier(0);
         read_A(buf, 0);
         read_W(buf, 0);
+        if (READS_FIRST) {
+          __builtin_amdgcn_sched_barrier(0);
+          stage_A(kt + 1, 0);
+        }
         P8_LGKM0();
         P8_BAR();
         mma(I0{}, I0{});
         P8_BAR();
         // P2 (th1, cp0)
-        stage_W(kt + 2, 0, C0{});
+        if (!READS_FIRST) stage_W(kt + 2, 0, C0{});
         __builtin_amdgcn_sched_barrier(0);
         read_A(buf, 1);
+        if (READS_FIRST) {
+          __builtin_amdgcn_sched_barrier(0);
+          stage_W(kt + 2, 0, C0{});
+        }
         P8_LGKM0();
         P8_BAR();
         mma(I1{}, I0{});
         P8_BAR();
         // P3 (th1, cp1)
-        stage_A(kt + 2, 1);
+        if (!READS_FIRST) stage_A(kt + 2, 1);
         __builtin_amdgcn_sched_barrier(0);
         read_W(buf, 1);
+        if (READS_FIRST) {
+          __builtin_amdgcn_sched_barrier(0);
+          stage_A(kt + 2, 1);
+        }
         P8_LGKM0();
         P8_BAR();
         mma(I1{}, I1{});
         P8_BAR();
         // P4 (th0, cp1)
-        stage_W(kt + 2, 1, C1{});
+        if (!READS_FIRST) stage_W(kt + 2, 1, C1{});
         __builtin_amdgcn_sched_barrier(0);
         read_A(buf, 0);
+        if (READS_FIRST) {
+          __builtin_amdgcn_sched_barrier(0);
+          stage_W(kt + 2, 1, C1{});
+        }
         if (kt + 2 < nK) P8_VMCNT(7);   // K-tile kt+1 complete; RW0 / RA1 / RW1 of kt+2 (7 pieces) stay in flight
         else P8_VMCNT(0);
         P8_LGKM0();
@@ -795,9 +818,17 @@ static bool p8_halo_ok(const GemmK& k, int mode) {
 
 int gcd_gemm_p8_launch(const GemmK& k, int mode, bool persist, hipStream_t s) {
 #ifdef GCD_ABLATION_BUILD
+  if (gcd_tune_get(GCD_TUNE_GEMM_IMPL) == 12 && persist && mode != GCD_GEMM_PLAIN && k.out_kind == GCD_OUT_F32 && !k.colstats) {
+    // A/B: the conv modes without s_setprio and with groups of 8 M-tiles (the PLAIN defaults)
+    if (p8_halo_ok(k, mode))
+      return k.R2 ? launch_p8<P8_CONV_HALO, 2048 + 96, 4>(k, s) : launch_p8<P8_CONV_HALO, 2048 + 96, 3>(k, s);
+    if (mode == GCD_GEMM_CONV3X3)
+      return k.R2 ? launch_p8<GCD_GEMM_CONV3X3, 2048 + 96, 4>(k, s) : launch_p8<GCD_GEMM_CONV3X3, 2048 + 96, 3>(k, s);
+    return k.R2 ? launch_p8<GCD_GEMM_TEMPORAL3, 2048 + 96, 4>(k, s) : launch_p8<GCD_GEMM_TEMPORAL3, 2048 + 96, 3>(k, s);
+  }
   {   // GCD_TUNE_GEMM_IMPL = 64 + ablation bits (PLAIN, persistent grids only)
     const int var = gcd_tune_get(GCD_TUNE_GEMM_IMPL) - 64;
-    if (var > 0 && var < 16 && mode == GCD_GEMM_PLAIN && persist && !k.colstats) {
+    if (var > 0 && var < 128 && mode == GCD_GEMM_PLAIN && persist && !k.colstats) {
       const int epi = k.out_kind == GCD_OUT_GEGLU ? 1 : (k.out_kind == GCD_OUT_F16 && !k.R1 && !k.R2 && !k.frame_alpha) ? 2 : 3;
       if (k.R2) return -1 + 0 * gcd_tune_get(0);   // (no ablation instantiations of the two-residual path)
 #define P8_ABL(V)                                                             \
@@ -810,6 +841,13 @@ int gcd_gemm_p8_launch(const GemmK& k, int mode, bool persist, hipStream_t s) {
         P8_ABL(2)
         P8_ABL(4)
         P8_ABL(8)
+        P8_ABL(16)
+        P8_ABL(32)
+        P8_ABL(64)
+        P8_ABL(48)
+        P8_ABL(80)
+        P8_ABL(96)
+        P8_ABL(112)
         default: break;
       }
 #undef P8_ABL

@@ -43,7 +43,8 @@ int gcd_device_info(int device, char* name, int cap, int* num_cus, size_t* hbm_b
  *   GCD_TUNE_GEMM_IMPL: 0 = automatic, 1 = general 128-row kernel, 2 = 256x320 tile kernels (the 8-phase
  *                       16x16x32 K loop where it applies, else the 32-deep ring kernel), 3 = 256x320 tile, ring
  *                       kernel only, 4 = 256x320 tile, never persistent; 10 = like 2, with the overlapped-epilogue
- *                       256x160 kernel (gemm_p8x, an experiment that lost its A/B) on the large fp16-output grids; 5 / 6 = general kernel, never / always
+ *                       256x160 kernel (gemm_p8x, an experiment that lost its A/B) on the large fp16-output grids;
+ *                       11 = like 0 without the halo-panel K loop of the stride-1 3x3 convolutions; 5 / 6 = general kernel, never / always
  *                       64-row tiles; 7 = like 0 (split-K allowed, used by tests); >= 32: ablation builds
  *   GCD_TUNE_ATTN_IMPL: 0 = automatic, other values select spatial-attention kernel variants
  *   GCD_TUNE_PP_MIN_TILES: automatic GEMM choice takes the ping-pong kernel from this many 256x320 tiles

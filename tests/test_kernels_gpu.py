@@ -403,7 +403,7 @@ def test_conv3x3_halo_panel(gpu, gemm_impl, frames, H, W, Cin, Cout, res):
         ref = ref + r1
     if r2 is not None:
         ref = ref + 0.5 * r2
-    a = x.permute(0, 2, 3, 1).reshape(M, Cin).half().to(gpu)
+    a = x.permute(0, 2, 3, 1).reshape(M, Cin).contiguous().half().to(gpu)
     out = torch.empty(M, Cout, device=gpu)
     kw = dict(M=M, mode=ops.GEMM_CONV3X3, bias=b.to(gpu),
               conv=dict(Cin=Cin, Hi=H, Wi=W, Ho=H, Wo=W, stride=1, upsample=0))
