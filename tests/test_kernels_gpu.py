@@ -26,16 +26,22 @@ def _gen(seed):
     return torch.Generator().manual_seed(seed)
 
 
-@pytest.fixture(params=[0, 2, 3, 6], ids=["auto", "tile256x320", "ring32", "tile64"], autouse=True)
-def gemm_impl(request):
-    """Every test of this module runs with the automatic GEMM kernel choice, with the 256x320 tile kernels forced
+_IMPL_IDS = {0: "auto", 2: "tile256x320", 3: "ring32", 6: "tile64"}
+
+
+def pytest_generate_tests(metafunc):
+    """Every GEMM test of this module runs with the automatic GEMM kernel choice, with the 256x320 tile kernels forced
     (2: the 8-phase 16x16x32 K loop of gemm_p8.hip wherever it applies; 3: the 32-deep ring kernel of gemm_pp.hip
-    only) and with the general kernel's 64-row tiles forced."""
+    only) and with the general kernel's 64-row tiles forced; tests that launch no GEMM run once."""
+    if "gemm_impl" in metafunc.fixturenames:
+        gemmish = any(k in metafunc.function.__name__ for k in ("gemm", "conv", "feedforward", "graph_capture"))
+        vals = [0, 2, 3, 6] if gemmish else [0]
+        metafunc.parametrize("gemm_impl", vals, ids=[_IMPL_IDS[v] for v in vals], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def gemm_impl(request):
     from gcd_amd import ops
-    # tests that launch no GEMM run once (automatic choice): the other kernel choices would repeat them unchanged
-    name = request.node.name
-    if request.param != 0 and not any(k in name for k in ("gemm", "conv", "feedforward", "graph_capture")):
-        pytest.skip("not a GEMM test: runs under the automatic kernel choice only")
     ops.tune_set(ops.TUNE_GEMM_IMPL, request.param)
     yield request.param
     ops.tune_set(ops.TUNE_GEMM_IMPL, 0)
