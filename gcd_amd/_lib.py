@@ -8,10 +8,14 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
-_PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libgcd_amd.so"
+import os
 
-ABI_VERSION = 5
+_PKG = Path(__file__).resolve().parent
+# GCD_AMD_LIB: another build of the SAME sources (tools/libgcd_amd_*.so: ablation / A-B variants) for the benchmark
+# tools; the product is the in-tree library next to this file.
+LIB_PATH = Path(os.environ["GCD_AMD_LIB"]).resolve() if os.environ.get("GCD_AMD_LIB") else _PKG / "libgcd_amd.so"
+
+ABI_VERSION = 6
 
 # GEMM modes / output kinds (mirror include/gcd_amd.h)
 GEMM_PLAIN, GEMM_CONV3X3, GEMM_TEMPORAL3 = 0, 1, 2
@@ -42,7 +46,7 @@ class GemmDesc(C.Structure):
         ("ld_ln_sum", C.c_int64),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("asym_pad", C.c_int32),
         ("colstats", C.c_void_p), ("out_blocked", C.c_int32), ("a_blocked", C.c_int32),
-        ("operand_bf16", C.c_int32),
+        ("operand_bf16", C.c_int32), ("sched", C.c_int32),
     ]
 
 
@@ -64,7 +68,7 @@ SIGNATURES = {
     "gcd_groupnorm_apply": (_i, [_vp, _i64, _i, _vp, _i64, _i, _i64, _i64, _vp, _vp, _vp, _i, _vp,
                                  _i64, _vp, _i64, _vp]),
     "gcd_layernorm_f16": (_i, [_vp, _i64, _i64, _i, _vp, _vp, _f, _vp, _i64, _i, _vp, _i64, _vp,
-                               _i64, _vp]),
+                               _i64, _i, _vp]),
     "gcd_attn_transpose_v": (_i, [_vp, _i64, _i, _i, _i, _vp, _i, _vp]),
     "gcd_attn_spatial_f16": (_i, [_vp, _i64, _vp, _i, _vp, _i64, _i, _i, _i, _i, _vp]),
     "gcd_attn_temporal_f16": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
@@ -82,7 +86,9 @@ SIGNATURES = {
     "gcd_im2col_t3_f16": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
     "gcd_col2im_t3_f32": (_i, [_vp, _vp, _i64, _i64, _i, _i, _i, _vp]),
     "gcd_rowblock_sum_f32": (_i, [_vp, _i64, _i64, _i, _i64, _vp, _vp]),
-    "gcd_groupnorm_bwd": (_i, [_vp, _i64, _vp, _i64, _i, _i64, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i64, _vp]),
+    "gcd_groupnorm_bwd_scratch_floats": (_i64, [_i, _i64, _i64]),
+    "gcd_groupnorm_bwd": (_i, [_vp, _i64, _vp, _i64, _i, _i64, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i64, _vp, _i64,
+                               _vp]),
     "gcd_layernorm_bwd": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp, _f, _vp, _i64, _vp, _vp, _vp]),
     "gcd_geglu_fwd_f32": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),
     "gcd_geglu_fwd_f16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),

@@ -489,11 +489,15 @@ def _gn_fwd(x, gamma, beta, rows_per_inst, eps, silu):
 def _gn_bwd(x, dy, stats, g32, b32, rows_per_inst, silu):
     M, Cc = x.shape
     ninst = M // rows_per_inst
-    AB = torch.zeros(ninst, Cc, 2, dtype=torch.float64, device=x.device)
+    lib = _lib.load()
+    AB = torch.empty(ninst, Cc, 2, dtype=torch.float64, device=x.device)
+    # per-chunk partial sums of the reduction pass (no atomics, nothing to zero): a few hundred KB
+    scratch = torch.empty(int(lib.gcd_groupnorm_bwd_scratch_floats(Cc, M, rows_per_inst)), dtype=_f32, device=x.device)
     dx = torch.empty_like(x)
-    check(_lib.load().gcd_groupnorm_bwd(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), Cc, M, rows_per_inst,
-                                        stats.data_ptr(), g32.data_ptr(), b32.data_ptr(), int(silu),
-                                        AB.data_ptr(), dx.data_ptr(), _ld(dx), _stream()),
+    check(lib.gcd_groupnorm_bwd(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), Cc, M, rows_per_inst,
+                                stats.data_ptr(), g32.data_ptr(), b32.data_ptr(), int(silu),
+                                AB.data_ptr(), scratch.data_ptr(), scratch.numel(), dx.data_ptr(), _ld(dx),
+                                _stream()),
           "gcd_groupnorm_bwd")
     ab = AB.sum(0).float()
     return dx, ab[:, 1].contiguous(), ab[:, 0].contiguous()

@@ -1049,6 +1049,147 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Temporal attention on the matrix pipe (round 4): one (clip, pixel, head) problem per WAVE — T <= 16 frames are one
+// 16 x 16 MFMA tile.  The kernel above does the two products of a problem with 16 lanes of v_dot2 / v_fma reading K and
+// V from LDS once per query (575 VALU + 56 ds_read_b128 wave-instructions per problem: VALU- and LDS-bound at 3 TB/s
+// on a 660 MB launch); here a problem costs ~100 wave-instructions and the launch streams:
+//   S^T = K Q^T   2 x v_mfma_f32_16x16x32_f16, operands straight from global memory: lane l holds row l & 15 (a frame),
+//                 head channels 8 (l >> 4) .. + 7 (+ 32 for the second K step) of K resp. Q — the MFMA A / B layouts ARE
+//                 16-byte row pieces, no LDS;
+//   softmax       S^T arrives as [key 4 (l >> 4) + e][query l & 15]: 4 scores per lane, the rest of a query's column sits
+//                 in lanes l ^ 16, l ^ 32, l ^ 48 (v_permlane16_swap / v_permlane32_swap); 4 v_exp_f32 per lane;
+//   O^T = V^T P^T 4 (x 2) x v_mfma_f32_16x16x16_f16: P^T in the accumulator layout IS the B operand; V^T (A operand:
+//                 lane = channel, 4 consecutive keys) is the one transposed read — V rows go through a wave-private
+//                 2.3 KB LDS tile (144-byte rows) and come back with ds_read_u16.  P enters as fp16 hi + fp16 lo
+//                 (two MFMAs per channel block, the pipe is idle anyway): the fp32 probabilities of the kernel above
+//                 to 2^-22, no new rounding on the path;
+//   store         O^T is [channel 16 b + 4 (l >> 4) + e][query l & 15]: four 8-byte pieces per lane, 32 contiguous bytes
+//                 per (frame row, 16-channel block).
+// A wave walks problems pid, pid + #waves, ... with the next problem's six 16-byte loads issued before the current
+// one's arithmetic.  Rows >= T (T = 14: two of sixteen) load a clamped row and are masked.
+// ------------------------------------------------------------------------------------------------
+#define TM_ROW 144   // bytes per V row in LDS: 128 + 16 pad (the four key quads of a ds_read_u16 land 16 banks apart)
+
+__global__ __launch_bounds__(256) void attn_temporal_mfma_kernel(const f16* __restrict__ qkv, int64_t ld,
+                                                                 f16* __restrict__ out, int64_t ldo,
+                                                                 int64_t nprob, int T, int HW, int heads) {
+  __shared__ __attribute__((aligned(16))) char vs_all[4 * 16 * TM_ROW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  char* const vs = vs_all + wave * 16 * TM_ROW;
+  const int r15 = lane & 15, q = lane >> 4;
+  const int C = heads * 64;
+  const int fr = r15 < T ? r15 : T - 1;           // the frame this lane loads (clamped: always a valid row)
+  const int nwaves = (int)gridDim.x * 4;
+  const int pid0 = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
+  if (pid0 >= nprob) return;
+  // problem = (clip b, pixel s, head h), h fastest: walked as a mixed-radix counter (one division set per wave, none per
+  // problem): (h, s, b) of pid0 and the digits of the stride
+  int ph = pid0 % heads, ps = (pid0 / heads) % HW, pb = pid0 / heads / HW;
+  const int dh = nwaves % heads, dsx = (nwaves / heads) % HW, db = nwaves / heads / HW;
+  const int64_t frow = (int64_t)fr * HW;
+  const f16* const lane_base = qkv + 8 * q;
+  auto advance = [&](int& h, int& s2, int& b) {
+    h += dh;
+    int c = h >= heads ? 1 : 0;
+    h -= c * heads;
+    s2 += dsx + c;
+    c = s2 >= HW ? 1 : 0;
+    s2 -= c * HW;
+    b += db + c;
+  };
+
+  f16x8 kf[2], qf[2], vf[2];
+  auto load = [&](int h, int s2, int b, f16x8 (&kk)[2], f16x8 (&qq)[2], f16x8 (&vv)[2]) {
+    const int64_t row = (int64_t)b * T * HW + s2 + frow;
+    const f16* src = lane_base + row * ld + h * 64;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      qq[k2] = *(const f16x8*)(src + 32 * k2);
+      kk[k2] = *(const f16x8*)(src + C + 32 * k2);
+      vv[k2] = *(const f16x8*)(src + 2 * C + 32 * k2);
+    }
+  };
+  load(ph, ps, pb, kf, qf, vf);
+  const float cs = 0.125f * 1.4426950408889634f;   // 1 / sqrt(64) in exp2 units
+  for (int64_t pid = pid0; pid < nprob; pid += nwaves) {
+    f16x8 kn[2], qn[2], vn[2];
+    const bool more = pid + nwaves < nprob;
+    int nh = ph, ns = ps, nb = pb;
+    advance(nh, ns, nb);
+    if (more) load(nh, ns, nb, kn, qn, vn);
+    // ---- V rows -> the wave's LDS tile (row = frame, 128 B + pad) ----
+    *(f16x8*)(vs + r15 * TM_ROW + 16 * q) = vf[0];
+    *(f16x8*)(vs + r15 * TM_ROW + 64 + 16 * q) = vf[1];
+    // ---- S^T = K Q^T ----
+    f32x4 st = {0.f, 0.f, 0.f, 0.f};
+    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[0], qf[0], st, 0, 0, 0);
+    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[1], qf[1], st, 0, 0, 0);
+    // ---- softmax over the keys 4 q + e of query r15 ----
+    float sc[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sc[e] = (4 * q + e < T) ? st[e] : -INFINITY;
+      mx = fmaxf(mx, sc[e]);
+    }
+    {
+      const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+      const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+    }
+    float pe[4], l = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pe[e] = __builtin_amdgcn_exp2f((sc[e] - mx) * cs);   // exp2(-inf) = 0 for the masked keys
+      l += pe[e];
+    }
+    {
+      const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(l), __float_as_uint(l), false, false);
+      l = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+      const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
+      l = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+    }
+    const float inv = 1.0f / l;
+    f16x4 phi, plo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float pv = pe[e] * inv;
+      phi[e] = (f16)pv;
+      plo[e] = (f16)(pv - (float)phi[e]);
+    }
+    // ---- O^T = V^T P^T, 16 channels at a time ----
+    f16* const dst = out + ((int64_t)pb * T * HW + ps + frow) * ldo + ph * 64 + 4 * q;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      f16x4 va;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) va[e] = *(const f16*)(vs + (4 * q + e) * TM_ROW + (16 * b + r15) * 2);
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      o = __builtin_amdgcn_mfma_f32_16x16x16f16(va, phi, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_16x16x16f16(va, plo, o, 0, 0, 0);
+      if (r15 < T) {
+        f16x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = (f16)o[e];
+        *(f16x4*)(dst + 16 * b) = ov;
+      }
+    }
+    ph = nh;
+    ps = ns;
+    pb = nb;
+    if (more) {
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        kf[k2] = kn[k2];
+        qf[k2] = qn[k2];
+        vf[k2] = vn[k2];
+      }
+    }
+  }
+}
+
 extern "C" int gcd_attn_temporal_f16(const void* qkv, int64_t ld, void* out, int64_t ldo, int clips,
                                      int T, int HW, int heads, void* stream) {
   GCD_CHECK_ARG(qkv && out, "gcd_attn_temporal_f16: null pointer");
@@ -1057,6 +1198,16 @@ extern "C" int gcd_attn_temporal_f16(const void* qkv, int64_t ld, void* out, int
   GCD_CHECK_ARG(ld % 8 == 0 && ld >= 3 * heads * 64 && ldo % 8 == 0 && ldo >= heads * 64,
                 "gcd_attn_temporal_f16: ld=%lld ldo=%lld", (long long)ld, (long long)ldo);
   const int64_t nprob = (int64_t)clips * HW * heads;
+  if (gcd_tune_get(GCD_TUNE_ATTN_IMPL) != 16 && nprob < (1ll << 31) - 8192) {
+    // one problem per wave on the matrix pipe; 7 workgroups (28 waves of 72 registers) per CU walk the problems.
+    // GCD_TUNE_ATTN_IMPL = 16 keeps the 16-lanes-per-problem VALU kernel below (A/B, tests).
+    int64_t mblocks = (nprob + 3) / 4;
+    if (mblocks > 1792) mblocks = 1792;
+    hipLaunchKernelGGL(attn_temporal_mfma_kernel, dim3((unsigned)mblocks), dim3(256), 0, (hipStream_t)stream,
+                       (const f16*)qkv, ld, (f16*)out, ldo, nprob, T, HW, heads);
+    GCD_CHECK_LAUNCH();
+    return 0;
+  }
   const int64_t blocks = (nprob + TPROB - 1) / TPROB;
   GCD_CHECK_ARG(blocks < (1ll << 31), "gcd_attn_temporal_f16: grid too large");
   const int smem = 2 * TPROB * TP_STRIDE(T);

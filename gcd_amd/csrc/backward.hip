@@ -196,7 +196,11 @@ __global__ __launch_bounds__(256) void rowblock_sum_kernel(const float* __restri
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy, int C,
     int64_t rows_per_inst, int rows_per_chunk, int txw, int kpass, const float* __restrict__ stats,
-    const float* __restrict__ gamma, const float* __restrict__ beta, int silu, double* __restrict__ AB) {
+    const float* __restrict__ gamma, const float* __restrict__ beta, int silu, float* __restrict__ partial) {
+  // Round 4: no atomics.  The first form folded every workgroup's (A_c, B_c) into AB with 8 fp64 device-scope
+  // atomics per column thread — ~1 M atomics on ~2 K cache lines per launch, which set the kernel's time (115 us
+  // for a 110 MB pass: 1 TB/s).  A workgroup now WRITES its chunk's sums, partial[inst][chunk][2][C] fp32, and
+  // gn_bwd_finalize_kernel folds the chunks in fp64; the row loop keeps four rows (8 x 16 B) per thread in flight.
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* red = (float*)smem_raw;   // [rpp][txw * 8]
   const int t = threadIdx.x;
@@ -209,6 +213,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(
   const int rpp = blockDim.x / txw;
   const int tx = t % txw, ty = t / txw;
   const bool on = ty < rpp;
+  float* const pout = partial + ((int64_t)inst * gridDim.x + chunk) * 2 * C;
   for (int kp = 0; kp < kpass; ++kp) {
     const int c = (tx + kp * txw) * 4;
     float mu[4], rs[4], ga[4], be[4];
@@ -221,42 +226,72 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(
       be[e] = beta[c + e];
     }
     float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
-    if (on) {
-      for (int64_t r = r0 + ty; r < r1; r += rpp) {
-        const f32x4 xv = *(const f32x4*)(x + (base + r) * ldx + c);
-        const f32x4 dv = *(const f32x4*)(dy + (base + r) * lddy + c);
+    auto acc = [&](const f32x4 xv, const f32x4 dv) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float xh = (xv[e] - mu[e]) * rs[e];
-          float dz = dv[e];
-          if (silu) dz *= dsilu_f(fmaf(ga[e], xh, be[e]));
-          a[e] += dz;
-          b[e] = fmaf(dz, xh, b[e]);
-        }
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (xv[e] - mu[e]) * rs[e];
+        float dz = dv[e];
+        if (silu) dz *= dsilu_f(fmaf(ga[e], xh, be[e]));
+        a[e] += dz;
+        b[e] = fmaf(dz, xh, b[e]);
       }
+    };
+    if (on) {
+      const float* xp = x + base * ldx + c;
+      const float* dp = dy + base * lddy + c;
+      int64_t r = r0 + ty;
+      for (; r + 3 * rpp < r1; r += 4 * rpp) {
+        f32x4 xv[4], dv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          xv[k] = *(const f32x4*)(xp + (r + k * rpp) * ldx);
+          dv[k] = *(const f32x4*)(dp + (r + k * rpp) * lddy);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc(xv[k], dv[k]);
+      }
+      for (; r < r1; r += rpp) acc(*(const f32x4*)(xp + r * ldx), *(const f32x4*)(dp + r * lddy));
       float* dst = red + ((int64_t)ty * txw + tx) * 8;
       *(f32x4*)dst = f32x4{a[0], a[1], a[2], a[3]};
       *(f32x4*)(dst + 4) = f32x4{b[0], b[1], b[2], b[3]};
     }
     __syncthreads();
     if (on && ty == 0) {
-      double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+      f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
       for (int y = 0; y < rpp; ++y) {
         const float* src = red + ((int64_t)y * txw + tx) * 8;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          sa[e] += (double)src[e];
-          sb[e] += (double)src[4 + e];
-        }
+        sa += *(const f32x4*)src;
+        sb += *(const f32x4*)(src + 4);
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        double* dst = AB + ((int64_t)inst * C + c + e) * 2;
-        atomicAdd(dst, sa[e]);
-        atomicAdd(dst + 1, sb[e]);
-      }
+      *(f32x4*)(pout + c) = sa;
+      *(f32x4*)(pout + C + c) = sb;
     }
     __syncthreads();
+  }
+}
+
+// AB[inst][c] = (sum over the chunks of A_c, of B_c) in fp64.  grid = (ceil(C / 64), ninst), block 256: thread
+// (channel t & 63, part t >> 6) folds every 4th chunk, the four parts meet in LDS.
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ partial, int nchunks, int C,
+                                                             double* __restrict__ AB) {
+  __shared__ double red[2][4][64];
+  const int inst = blockIdx.y, cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+    const float* src = partial + (int64_t)inst * nchunks * 2 * C + c;
+    for (int k = part; k < nchunks; k += 4) {
+      a += (double)src[(int64_t)k * 2 * C];
+      b += (double)src[(int64_t)k * 2 * C + C];
+    }
+  }
+  red[0][part][cl] = a;
+  red[1][part][cl] = b;
+  __syncthreads();
+  if (part == 0 && c < C) {
+    double* dst = AB + ((int64_t)inst * C + c) * 2;
+    dst[0] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    dst[1] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
   }
 }
 
@@ -827,14 +862,36 @@ extern "C" int gcd_rowblock_sum_f32(const float* x, int64_t ldx, int64_t M, int 
   return 0;
 }
 
+// Row chunks per instance of the GroupNorm backward's reduction pass, and with them the scratch it needs:
+// >= 64 rows per chunk, ~700 workgroups over the launch.
+static int gn_bwd_chunks(int64_t rows_per_inst, int ninst, int* rows_per_chunk) {
+  int64_t want = (704 + ninst - 1) / ninst;
+  int64_t nchunks = (rows_per_inst + 63) / 64;
+  if (nchunks > want) nchunks = want;
+  if (nchunks < 1) nchunks = 1;
+  const int rpc = (int)((rows_per_inst + nchunks - 1) / nchunks);
+  nchunks = (rows_per_inst + rpc - 1) / rpc;
+  if (rows_per_chunk) *rows_per_chunk = rpc;
+  return (int)nchunks;
+}
+
+extern "C" int64_t gcd_groupnorm_bwd_scratch_floats(int C, int64_t M, int64_t rows_per_inst) {
+  if (C <= 0 || M <= 0 || rows_per_inst <= 0 || M % rows_per_inst != 0) return 0;
+  const int ninst = (int)(M / rows_per_inst);
+  return (int64_t)ninst * gn_bwd_chunks(rows_per_inst, ninst, nullptr) * 2 * C;
+}
+
 extern "C" int gcd_groupnorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int C, int64_t M,
                                  int64_t rows_per_inst, const float* stats, const float* gamma,
-                                 const float* beta, int silu, double* AB_zeroed, float* dx, int64_t lddx,
-                                 void* stream) {
-  GCD_CHECK_ARG(x && dy && stats && gamma && beta && AB_zeroed && dx, "gcd_groupnorm_bwd: null pointer");
+                                 const float* beta, int silu, double* AB, float* scratch, int64_t scratch_floats,
+                                 float* dx, int64_t lddx, void* stream) {
+  GCD_CHECK_ARG(x && dy && stats && gamma && beta && AB && scratch && dx, "gcd_groupnorm_bwd: null pointer");
   GCD_CHECK_ARG(C > 0 && C % 32 == 0 && C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0,
                 "gcd_groupnorm_bwd: C=%d", C);
   GCD_CHECK_ARG(rows_per_inst > 0 && M > 0 && M % rows_per_inst == 0, "gcd_groupnorm_bwd: M / rows_per_inst");
+  GCD_CHECK_ARG(scratch_floats >= gcd_groupnorm_bwd_scratch_floats(C, M, rows_per_inst) && ((uintptr_t)scratch & 15) == 0,
+                "gcd_groupnorm_bwd: scratch of %lld floats, need %lld (gcd_groupnorm_bwd_scratch_floats), 16-byte aligned",
+                (long long)scratch_floats, (long long)gcd_groupnorm_bwd_scratch_floats(C, M, rows_per_inst));
   const int ninst = (int)(M / rows_per_inst);
   hipStream_t s = (hipStream_t)stream;
   const int cv4 = C / 4;
@@ -842,16 +899,13 @@ extern "C" int gcd_groupnorm_bwd(const float* x, int64_t ldx, const float* dy, i
   while (cv4 % kpass != 0 || cv4 / kpass > 256) ++kpass;
   const int txw = cv4 / kpass;
   const int rpp = 256 / txw;
-  // ~1500 workgroups over the launch, at least 4 rows per row lane and chunk
-  int64_t want = (1536 + ninst - 1) / ninst;
-  int64_t nchunks = (rows_per_inst + 4 * rpp - 1) / (4 * rpp);
-  if (nchunks > want) nchunks = want;
-  if (nchunks < 1) nchunks = 1;
-  const int rpc = (int)((rows_per_inst + nchunks - 1) / nchunks);
-  nchunks = (rows_per_inst + rpc - 1) / rpc;
+  int rpc = 0;
+  const int nchunks = gn_bwd_chunks(rows_per_inst, ninst, &rpc);
   GCD_CHECK_ARG(ninst <= 65535 && C * 24 <= 160 * 1024 - 512, "gcd_groupnorm_bwd: %d instances / C=%d too large", ninst, C);
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3((unsigned)nchunks, ninst), dim3(256), rpp * txw * 8 * sizeof(float), s, x,
-                     ldx, dy, lddy, C, rows_per_inst, rpc, txw, kpass, stats, gamma, beta, silu, AB_zeroed);
+                     ldx, dy, lddy, C, rows_per_inst, rpc, txw, kpass, stats, gamma, beta, silu, scratch);
+  GCD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((C + 63) / 64, ninst), dim3(256), 0, s, scratch, nchunks, C, AB);
   GCD_CHECK_LAUNCH();
   int achunks = (int)((rows_per_inst + 63) / 64);
   if (achunks > 1024) achunks = 1024;
@@ -859,7 +913,7 @@ extern "C" int gcd_groupnorm_bwd(const float* x, int64_t ldx, const float* dy, i
   static GcdPerDeviceOnce attr_once;
   if (C * 24 > 48 * 1024) GCD_CHECK_HIP(attr_once.opt_in((const void*)gn_bwd_apply_kernel, 160 * 1024 - 512));
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(achunks, ninst), dim3(256), C * 24, s, x, ldx, dy, lddy, C,
-                     rows_per_inst, arpc, stats, gamma, beta, silu, AB_zeroed, dx, lddx);
+                     rows_per_inst, arpc, stats, gamma, beta, silu, AB, dx, lddx);
   GCD_CHECK_LAUNCH();
   return 0;
 }

@@ -86,15 +86,17 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True,
     return LIB
 
 
-def _build_ablation(verbose: bool) -> Path:
+def _build_ablation(verbose: bool, name: str = "ablate", defines=("-DGCD_ABLATION_BUILD",)) -> Path:
+    """A second library beside the product one (tools/libgcd_amd_<name>.so) from the same sources with extra defines:
+    the ablation build, and the A/B variants of tools/ab_sweep.sh (loaded through GCD_AMD_LIB, see _lib.py)."""
     hipcc = _hipcc()
-    objdir = CSRC / "build" / "ablate"
+    objdir = CSRC / "build" / name
     objdir.mkdir(parents=True, exist_ok=True)
-    out = ROOT / "tools" / "libgcd_amd_ablate.so"
+    out = ROOT / "tools" / f"libgcd_amd_{name}.so"
     procs = []
     for src in SOURCES:
         obj = objdir / (src + ".o")
-        cmd = [hipcc, *FLAGS, "-DGCD_ABLATION_BUILD", "-c", str(CSRC / src), "-o", str(obj)]
+        cmd = [hipcc, *FLAGS, *defines, "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print("[gcd_amd.build]", " ".join(cmd), flush=True)
         procs.append((src, obj, subprocess.Popen(cmd, cwd=str(objdir))))
@@ -110,6 +112,9 @@ def _build_ablation(verbose: bool) -> Path:
 if __name__ == "__main__":
     if "--ablation" in sys.argv:
         print(build(ablation=True))
+    elif "--epi-wt" in sys.argv:      # write-through epilogue stores (gemm_common.h, GCD_EPI_WT): A/B library
+        mask = int(sys.argv[sys.argv.index("--epi-wt") + 1])
+        print(_build_ablation(True, f"wt{mask}", (f"-DGCD_EPI_WT={mask}",)))
     else:
         build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv)
         print(LIB)

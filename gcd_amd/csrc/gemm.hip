@@ -446,6 +446,7 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
   k.out_blocked = d->out_blocked ? 1 : 0;
   k.a_blocked = d->a_blocked ? 1 : 0;
   k.operand_bf16 = d->operand_bf16 ? 1 : 0;
+  k.sched = d->sched & 1;
   hipStream_t s = (hipStream_t)stream;
 
   // kernel choice: the 256 x 320 ping-pong kernel whenever the grid fills most of the chip with

@@ -49,7 +49,34 @@ struct GemmK {
   // gemm_p8.hip: operand extents in bytes (buffer descriptors), frames of a conv input
   uint32_t a_bytes, w_bytes;
   int a_frames;
+  // gcd_gemm_desc.sched (gemm_p8.hip): bit 0 = every XCD walks its share of the tiles from the END (pure scheduling)
+  int sched;
 };
+
+// Global stores of the row-major fast epilogues, plain or write-through by a BUILD switch (-DGCD_EPI_WT=mask: 1 the
+// GEGLU path, 2 the fp16 path, 4 the fp32 / residual path; 0 = plain stores, the default).  sc1 stores do not keep the
+// written line in the XCD's L2 (MI355X_MICROARCH.md, "stores of each flavour"): a tile's output is never read again by
+// its launch, the A / W panels its neighbours re-read are.  A build switch, not a descriptor bit, so that the A/B
+// (tools/ab_sweep.sh: a second library, GCD_AMD_LIB) leaves the code generation of the product kernels untouched.
+// Inline asm because clang has no builtin for a flat global store with a cache policy; the trailing s_nop covers the
+// "VMEM store of more than 8 bytes -> VALU write of the data registers" hazard the compiler cannot see through the asm
+// (the in-order vmcnt the compiler derives stays a safe over-estimate: an unknown extra store in the queue only makes a
+// counted wait stricter).
+#ifndef GCD_EPI_WT
+#define GCD_EPI_WT 0
+#endif
+template <bool WT, typename V>
+__device__ __forceinline__ void gcd_store16(void* ptr, const V& v) {
+  static_assert(sizeof(V) == 16, "16-byte vector");
+  if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v));
+  else *(V*)ptr = v;
+}
+template <bool WT, typename V>
+__device__ __forceinline__ void gcd_store8(void* ptr, const V& v) {
+  static_assert(sizeof(V) == 8, "8-byte vector");
+  if constexpr (WT) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(ptr), "v"(v));
+  else *(V*)ptr = v;
+}
 
 // gemm_pp.hip: the 256 x 320 ping-pong kernel.
 bool gcd_gemm_pp_supported(const GemmK& k, int mode);
@@ -371,9 +398,9 @@ __device__ __forceinline__ void gcd_epi_f32_rows_full(const GemmK& p, ACC& acc, 
         f16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (f16)v[e];
-        *(f16x4*)(op16 + (4 * j + qq) * so + 32 * i) = o;
+        gcd_store8<(GCD_EPI_WT & 4) != 0>(op16 + (4 * j + qq) * so + 32 * i, o);
       } else {
-        *(f32x4*)(op + (4 * j + qq) * so + 32 * i) = v;
+        gcd_store16<(GCD_EPI_WT & 4) != 0>(op + (4 * j + qq) * so + 32 * i, v);
       }
     }
     if ((HAS_R1 || HAS_R2) && b + D < 10) fetch(b + D, b % D);
@@ -423,7 +450,7 @@ __device__ __forceinline__ void gcd_epi_geglu_rows_full(const GemmK& p, ACC& acc
       const int tt = it * 64 + lane;
       const int row = tt / 10, ch = tt - row * 10;
       const f16x8 v = *(const f16x8*)(stage + row * GCD_EPI_ROW_F16 + ch * 16);
-      *(f16x8*)(outp + (int64_t)(32 * j + row) * rs + ch * 8) = v;
+      gcd_store16<(GCD_EPI_WT & 1) != 0>(outp + (int64_t)(32 * j + row) * rs + ch * 8, v);
     }
   }
 }
@@ -444,7 +471,7 @@ __device__ __forceinline__ void gcd_epi_f16_rows_full(const GemmK& p, ACC& acc, 
       const int tt = it * 64 + lane;
       const int row = tt / 20, ch = tt - row * 20;
       const f16x8 v = *(const f16x8*)(stage + row * GCD_EPI_ROW_H160 + ch * 16);
-      *(f16x8*)(outp + (int64_t)row * p.ldo + ch * 8) = v;
+      gcd_store16<(GCD_EPI_WT & 2) != 0>(outp + (int64_t)row * p.ldo + ch * 8, v);
     }
   }
 }

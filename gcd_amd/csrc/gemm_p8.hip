@@ -213,6 +213,15 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
   // Tile Lx of the linear order -> (m0, n0), DMA source offsets, staged epilogue addends.
   auto set_tile = [&](int Lx) {
     int tile_m, tile_n;
+    if (!SPLITK && (p.sched & 1)) {
+      // gcd_gemm_desc.sched bit 0: the XCD's share [start, start + cnt) of the tile order is walked from its END —
+      // position Lx of the walk is tile 2 start + cnt - 1 - Lx (pure scheduling; the share is re-derived here, once
+      // per tile, so that nothing of it stays live through the K loop)
+      const int nblk = PERSIST ? p.tiles_m * p.tiles_n : (int)gridDim.x;
+      const int q = nblk >> 3, r = nblk & 7, xcd = blockIdx.x & 7;
+      const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+      Lx = 2 * start + q + (xcd < r ? 1 : 0) - 1 - Lx;
+    }
     kz = SPLITK ? Lx % p.splitk : 0;
     {
       const int Lt = SPLITK ? Lx / p.splitk : Lx;

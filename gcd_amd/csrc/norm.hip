@@ -10,6 +10,23 @@
 //     normalised + SiLU'd, together with an optional raw fp16 copy for the 1x1 skip conv.
 #include "common.h"
 
+// Walk orders of the two big streaming kernels (GroupNorm apply, LayerNorm): position v of the dispatch order -> block
+// of rows.  Pure scheduling (see gcd_gemm_desc.sched in gcd_amd.h): a kernel that reads what the previous launch wrote
+// finds in the 256 MB Infinity Cache what that launch wrote LAST.
+//   0 front to back      1 back to front
+//   2 / 3  the tensor as eight contiguous regions walked concurrently, position v -> region v % 8 — the order in which
+//          a persistent GEMM's eight XCD shares are written — every region back to front (2) / front to back (3)
+__device__ __forceinline__ int64_t gcd_walk(int64_t v, int64_t nb, int order) {
+  if (order == 0) return v;
+  if (order == 1) return nb - 1 - v;
+  const int64_t q = nb >> 3;
+  const int rem = (int)(nb & 7), r = (int)(v & 7);
+  const int64_t pos = v >> 3;
+  const int64_t start = r < rem ? r * (q + 1) : rem * (q + 1) + (r - rem) * q;
+  const int64_t len = q + (r < rem ? 1 : 0);
+  return order == 2 ? start + len - 1 - pos : start + pos;
+}
+
 // ------------------------------------------------------------------------------------------------
 // GroupNorm statistics
 // grid = (nchunks, ninst).  A thread keeps ONE float4 column for the whole chunk (block = txw
@@ -237,10 +254,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
   const int C = C1 + C2;
   float* sh = sc + C;            // [C] shift
   const int cg = C / 32;
-  const bool rev = (silu & 2) != 0;     // walk the tensor from its end (see gcd_amd.h)
+  const int order = (silu >> 1) & 3;    // walk order of the (instance, chunk) blocks (gcd_walk; see gcd_amd.h)
   silu &= 1;
-  const int inst = rev ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
-  const int chunk = rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+  const int64_t blk = gcd_walk((int64_t)blockIdx.y * gridDim.x + blockIdx.x, (int64_t)gridDim.x * gridDim.y, order);
+  const int inst = (int)(blk / gridDim.x);
+  const int chunk = (int)(blk - (int64_t)inst * gridDim.x);
   const int t = threadIdx.x;
   for (int c = t; c < C; c += 256) {
     const int g = c / cg;
@@ -357,12 +375,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
     const float* __restrict__ x, int64_t ldx, int64_t M, int C, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, const float* __restrict__ addvec, int64_t ld_addvec,
     int rows_per_vec, float* __restrict__ sum_out, int64_t ld_sum, f16* __restrict__ y,
-    int64_t ldy) {
+    int64_t ldy, int order) {
   const int lane = threadIdx.x & 63;
   const int cv4 = C >> 2;
-  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
-  for (int64_t m = wave0; m < M; m += nwaves) {
+  const int64_t nrb = (M + 3) >> 2;   // blocks of 4 rows (one per wave), walked in `order`
+  for (int64_t pos = blockIdx.x; pos < nrb; pos += gridDim.x) {
+    const int64_t m = gcd_walk(pos, nrb, order) * 4 + (threadIdx.x >> 6);
+    if (m >= M) continue;
     const float* row = x + m * ldx;
     const float* av = addvec ? addvec + (m / rows_per_vec) * ld_addvec : nullptr;
     f32x4 v[NV];
@@ -425,17 +444,19 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(
     const float* __restrict__ x, int64_t ldx, int64_t M, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, const float* __restrict__ addvec, int64_t ld_addvec,
     int rows_per_vec, float* __restrict__ sum_out, int64_t ld_sum, f16* __restrict__ y,
-    int64_t ldy) {
+    int64_t ldy, int order) {
   constexpr int C = NV * LPR * 4, RS = LPR * 4;   // RS: floats between a lane's consecutive vectors
+  constexpr int RPB = 256 / LPR;                  // rows per workgroup
   const int l16 = threadIdx.x & (LPR - 1);
-  const int64_t grp0 = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
-  const int64_t ngrp = (int64_t)gridDim.x * (256 / LPR);
+  const int64_t nrb = (M + RPB - 1) / RPB;        // row blocks, walked in `order`
   auto row_sum = [](float v) {
     v = row16_sum(v);
     if (LPR == 32) v += __shfl_xor(v, 16);
     return v;
   };
-  for (int64_t m = grp0; m < M; m += ngrp) {
+  for (int64_t pos = blockIdx.x; pos < nrb; pos += gridDim.x) {
+    const int64_t m = gcd_walk(pos, nrb, order) * RPB + threadIdx.x / LPR;
+    if (m >= M) continue;   // (whole 16- / 32-lane row groups leave together: the DPP sums stay inside a group)
     const float* row = x + m * ldx + l16 * 4;
     f32x4 v[NV];
 #pragma unroll
@@ -474,7 +495,7 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(
 extern "C" int gcd_layernorm_f16(const float* x, int64_t ldx, int64_t M, int C, const float* gamma,
                                  const float* beta, float eps, const float* addvec,
                                  int64_t ld_addvec, int rows_per_vec, float* sum_out,
-                                 int64_t ld_sum, void* y16, int64_t ldy, void* stream) {
+                                 int64_t ld_sum, void* y16, int64_t ldy, int order, void* stream) {
   GCD_CHECK_ARG(x && gamma && beta && y16, "gcd_layernorm_f16: null pointer");
   GCD_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 2048, "gcd_layernorm_f16: M=%lld C=%d",
                 (long long)M, C);
@@ -482,6 +503,7 @@ extern "C" int gcd_layernorm_f16(const float* x, int64_t ldx, int64_t M, int C, 
   if (addvec)
     GCD_CHECK_ARG(rows_per_vec > 0 && ld_addvec % 4 == 0, "gcd_layernorm_f16: addvec geometry");
   if (sum_out) GCD_CHECK_ARG(ld_sum % 4 == 0, "gcd_layernorm_f16: ld_sum alignment");
+  GCD_CHECK_ARG(order >= 0 && order <= 3, "gcd_layernorm_f16: order=%d (0..3)", order);
   hipStream_t s = (hipStream_t)stream;
   if (C == 320 || C == 640) {   // 16 / 32 lanes per row, 5 vectors per lane
     const int rpb = C == 320 ? 16 : 8;   // rows per 256-thread block
@@ -489,10 +511,10 @@ extern "C" int gcd_layernorm_f16(const float* x, int64_t ldx, int64_t M, int C, 
     if (blocks16 > 8192) blocks16 = 8192;
     if (C == 320)
       hipLaunchKernelGGL((layernorm16_kernel<5, 16>), dim3((unsigned)blocks16), dim3(256), 0, s, x, ldx, M,
-                         gamma, beta, eps, addvec, ld_addvec, rows_per_vec, sum_out, ld_sum, (f16*)y16, ldy);
+                         gamma, beta, eps, addvec, ld_addvec, rows_per_vec, sum_out, ld_sum, (f16*)y16, ldy, order);
     else
       hipLaunchKernelGGL((layernorm16_kernel<5, 32>), dim3((unsigned)blocks16), dim3(256), 0, s, x, ldx, M,
-                         gamma, beta, eps, addvec, ld_addvec, rows_per_vec, sum_out, ld_sum, (f16*)y16, ldy);
+                         gamma, beta, eps, addvec, ld_addvec, rows_per_vec, sum_out, ld_sum, (f16*)y16, ldy, order);
     GCD_CHECK_LAUNCH();
     return 0;
   }
@@ -502,7 +524,7 @@ extern "C" int gcd_layernorm_f16(const float* x, int64_t ldx, int64_t M, int C, 
 #define GCD_LN_LAUNCH(NV)                                                                        \
   hipLaunchKernelGGL(layernorm_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, M, C, \
                      gamma, beta, eps, addvec, ld_addvec, rows_per_vec, sum_out, ld_sum,         \
-                     (f16*)y16, ldy)
+                     (f16*)y16, ldy, order)
   switch (nv) {
     case 1: GCD_LN_LAUNCH(1); break;
     case 2: GCD_LN_LAUNCH(2); break;

@@ -33,6 +33,16 @@ COUT_PAD = 16   # last conv: output channels padded to the GEMM N granule
 
 
 _GN_REVERSE = os.environ.get("GCD_GN_REVERSE", "1") != "0"   # A/B switch (see ops.groupnorm_apply)
+# Walk directions of the big streaming launches (GEMMs on the 8-phase kernel, LayerNorm, GroupNorm apply) — pure
+# scheduling, results bit-identical.  What a launch wrote LAST is what the 256 MB Infinity Cache still holds when the
+# next one starts, so a consumer that walks in the OPPOSITE direction of its producer turns part of its HBM reads into
+# cache hits (gcd_gemm_desc.sched, the `order` of gcd_layernorm_f16 / gcd_groupnorm_apply).
+#   0  everything front to back, except the GroupNorm apply behind a GEMM that left its column sums (back to front)
+#   1  zig-zag: every big launch walks opposite to the previous one; the norms use the GEMM's region order (eight
+#      contiguous shares walked concurrently); the attention cores count as front to back
+#   2  as 1 with whole-tensor orders for the norms        3  as 0 with the region order for that GroupNorm
+#   4  as 0 plus every LayerNorm back to front (region order)
+_ZIGZAG = int(os.environ.get("GCD_ZIGZAG", "0"))
 _ITEMSIZE = {torch.float16: 2, torch.float32: 4, torch.float64: 8, torch.uint8: 1}
 
 
@@ -135,6 +145,7 @@ class UNetEngine:
         # epilogue pays for it in VALU and 8-byte fp16 stores), so it is off unless GCD_FUSE_LN=1.
         self.fuse_layernorm = os.environ.get("GCD_FUSE_LN", "0") == "1"
         self.taps: Optional[dict] = None   # debug: name -> NCHW fp32 clone of every block output
+        self._last_dir = 1                  # direction of the last big launch (zig-zag schedule, _ZIGZAG)
         self._side_streams: Dict[int, "torch.cuda.Stream"] = {}
 
     def side_stream(self, device) -> "torch.cuda.Stream":
@@ -315,7 +326,7 @@ class UNetEngine:
         C = x1.shape[1] + (0 if x2 is None else x2.shape[1])
         ninst = M // rows
         stats = ws.alloc((ninst * 64,), torch.float32)
-        reverse = False
+        order = 0
         cs1, cs2 = ws.attached(x1), ws.attached(x2)
         if cs1 is not None and (x2 is None or cs2 is not None) and rows % 64 == 0:
             # the GEMM epilogues that wrote x1 (and x2) left per-64-row column sums behind: no
@@ -324,14 +335,18 @@ class UNetEngine:
                                              M, rows, eps, stats)
             partial = None
             # nothing has read the tensor since the GEMM wrote it front to back: start at its tail
-            reverse = _GN_REVERSE and x2 is None
+            if _GN_REVERSE and x2 is None and _ZIGZAG in (0, 3, 4):
+                order = 2 if _ZIGZAG == 3 else 1
         else:
             nch = ops.gn_nchunks(rows, ninst)
             partial = ws.alloc((ninst * nch * 64,), torch.float64)
             ops.groupnorm_stats(x1, x2, rows, eps, partial, stats, nch)
+            self._walked(0)      # the statistics pass read the tensor front to back
+        if _ZIGZAG in (1, 2):
+            order = self._norm_order()
         y = ws.alloc((M, C), torch.float16)
         raw = ws.alloc((M, C), torch.float16) if want_raw else None
-        ops.groupnorm_apply(x1, x2, rows, stats, affine[0], affine[1], silu, y, raw, reverse=reverse)
+        ops.groupnorm_apply(x1, x2, rows, stats, affine[0], affine[1], silu, y, raw, order=order)
         ws.release(partial, stats)
         return y, raw
 
@@ -342,17 +357,40 @@ class UNetEngine:
         ws = self.ws
         if ops.gemm(a16, w16, out, probe_colstats=True, **kw):
             cs = ws.alloc((2 * (kw["M"] // 64), w16.shape[0]), torch.float32)
-            ops.gemm(a16, w16, out, colstats=cs, **kw)
+            self._gemm(a16, w16, out, colstats=cs, **kw)
             ws.attach(out, cs)
         else:
-            ops.gemm(a16, w16, out, **kw)
+            self._gemm(a16, w16, out, **kw)
             ws.attach(out, None)
         return out
 
+    # ---- walk directions (see _ZIGZAG) ----
+    def _walked(self, d: int) -> None:
+        """Record the direction (0 front to back, 1 back to front) of a big launch that chose none."""
+        self._last_dir = d
+
+    def _next_dir(self) -> int:
+        d = 1 - self._last_dir
+        self._last_dir = d
+        return d
+
+    def _norm_order(self) -> int:
+        d = self._next_dir()
+        if _ZIGZAG == 1:
+            return 2 if d else 3
+        return d
+
+    def _gemm(self, a16, w16, out, **kw):
+        """`ops.gemm` with the walk direction of the zig-zag schedule (gcd_gemm_desc.sched bit 0)."""
+        if _ZIGZAG in (1, 2):
+            kw["sched"] = self._next_dir()
+        return ops.gemm(a16, w16, out, **kw)
+
     def _ln(self, x, affine, addvec=None, rows_per_vec=1, sum_out=None):
         y = self.ws.alloc(tuple(x.shape), torch.float16)
+        order = self._norm_order() if _ZIGZAG in (1, 2) else (2 if _ZIGZAG == 4 else 0)
         ops.layernorm(x, affine[0], affine[1], y, addvec=addvec, rows_per_vec=rows_per_vec,
-                      sum_out=sum_out)
+                      sum_out=sum_out, order=order)
         return y
 
     def _mlp_small(self, x, m, out=None, accumulate=False):
@@ -390,7 +428,7 @@ class UNetEngine:
         xs = ws.alloc((M, cout), torch.float32)
         conv2 = dict(conv, Cin=cout)
         if L["wskip"] is not None:
-            ops.gemm(raw16, L["wskip"], xs, M=M, bias=L["bskip"])
+            self._gemm(raw16, L["wskip"], xs, M=M, bias=L["bskip"])
             ws.release(raw16)
             self._gemm_gn(a16, L["w2"], xs, M=M, mode=GEMM_CONV3X3, bias=L["b2"], r1=xs, conv=conv2)
         else:
@@ -419,9 +457,9 @@ class UNetEngine:
         # the hidden tensor only lives between these two GEMMs: where both run on the ping-pong kernel it
         # is kept tile-blocked ([M/256][N/320][256][160]: whole 128-byte lines per store, §7 of DESIGN.md)
         blocked = epi.get("ln") is None and ops.gemm_hidden_blocked_ok(M, F["w1"].shape[0], F["w2"].shape[0])
-        ops.gemm(a16, F["w1"], hid, M=M, bias=F["b1"], out_kind=OUT_GEGLU, out_blocked=blocked)
+        self._gemm(a16, F["w1"], hid, M=M, bias=F["b1"], out_kind=OUT_GEGLU, out_blocked=blocked)
         ws.release(a16)
-        ops.gemm(hid, F["w2"], epi.pop("out"), M=M, bias=F["b2"], a_blocked=blocked, **epi)
+        self._gemm(hid, F["w2"], epi.pop("out"), M=M, bias=F["b2"], a_blocked=blocked, **epi)
         ws.release(hid)
 
     def _transformer(self, L, x, st):
@@ -445,7 +483,7 @@ class UNetEngine:
 
         blocks = L["blocks"]
         nxt, req = ln_req(blocks[0][0]["ln1"])
-        ops.gemm(a16, L["win"], xs, M=M, bias=L["bin"], ln=req)
+        self._gemm(a16, L["win"], xs, M=M, bias=L["bin"], ln=req)
         ws.release(a16)
         pos = self._pos_embed(L["pos"], N, T)
         S_pad = (HW + 63) // 64 * 64
@@ -454,16 +492,17 @@ class UNetEngine:
             # ---- spatial BasicTransformerBlock (attention.py:551-572) ----
             a16 = nxt if fuse else self._ln(xs, sb["ln1"])
             qkv = ws.alloc((M, 3 * Cc), torch.float16)
-            ops.gemm(a16, sb["attn"]["wqkv"], qkv, M=M, out_kind=OUT_F16)
+            self._gemm(a16, sb["attn"]["wqkv"], qkv, M=M, out_kind=OUT_F16)
             ws.release(a16)
             vt = ws.alloc((N * heads * 64 * S_pad,), torch.float16)
             ops.attn_transpose_v(qkv, N, HW, heads, vt, S_pad)
             ao = ws.alloc((M, Cc), torch.float16)
             ops.attn_spatial(qkv, vt, S_pad, ao, N, HW, heads, q_prescaled=True)
+            self._walked(0)
             ws.release(qkv, vt)
             # x = attn1 + x ; x = attn2 + x  (attn2 == per-frame vector, one key)
             nxt, req = ln_req(sb["ln3"])
-            ops.gemm(ao, sb["attn"]["wo"], xs, M=M, bias=sb["attn"]["bo"], r1=xs,
+            self._gemm(ao, sb["attn"]["wo"], xs, M=M, bias=sb["attn"]["bo"], r1=xs,
                      rowvec=ca[sb["ca"]], rows_per_vec=HW, ln=req)
             ws.release(ao)
             a16 = nxt if fuse else self._ln(xs, sb["ln3"])
@@ -476,13 +515,14 @@ class UNetEngine:
             self._ff(tb["ff_in"], a16, M, out=xm, r1=xm, ln=req)
             a16 = nxt if fuse else self._ln(xm, tb["ln1"])
             qkv = ws.alloc((M, 3 * Cc), torch.float16)
-            ops.gemm(a16, tb["attn"]["wqkv"], qkv, M=M, out_kind=OUT_F16)
+            self._gemm(a16, tb["attn"]["wqkv"], qkv, M=M, out_kind=OUT_F16)
             ws.release(a16)
             ao = ws.alloc((M, Cc), torch.float16)
             ops.attn_temporal(qkv, ao, N // T, T, HW, heads)
+            self._walked(0)
             ws.release(qkv)
             nxt, req = ln_req(tb["ln3"])
-            ops.gemm(ao, tb["attn"]["wo"], xm, M=M, bias=tb["attn"]["bo"], r1=xm,
+            self._gemm(ao, tb["attn"]["wo"], xm, M=M, bias=tb["attn"]["bo"], r1=xm,
                      rowvec=ca[tb["ca"]], rows_per_vec=T * HW, ln=req)
             ws.release(ao)
             a16 = nxt if fuse else self._ln(xm, tb["ln3"])
@@ -630,6 +670,7 @@ class UNetEngine:
         if H % (1 << (nlev - 1)) or W % (1 << (nlev - 1)):
             raise ValueError(f"latent size {H}x{W} must be divisible by {1 << (nlev - 1)}")
         ws.reset((N, H, W, T))
+        self._last_dir = 1
         st = dict(N=N, T=T, H=H, W=W)
         st["alphas"] = alphas if alphas is not None else self.blend_alphas(image_only_indicator, N, T)
         ctx2d = context.detach().float().reshape(N, -1).contiguous()
@@ -694,7 +735,7 @@ class UNetEngine:
         a16, _ = self._gn(h, None, H * W, 1e-5, P["out_gn"], True, False)
         ws.release(h)
         tok = ws.alloc((M, COUT_PAD), torch.float32)
-        ops.gemm(a16, P["out_w"], tok, M=M, mode=GEMM_CONV3X3, bias=P["out_b"],
+        self._gemm(a16, P["out_w"], tok, M=M, mode=GEMM_CONV3X3, bias=P["out_b"],
                  conv=dict(Cin=u.model_channels, Hi=H, Wi=W, Ho=H, Wo=W, stride=1, upsample=0),
                  alg_flops_scale=u.out_channels / COUT_PAD)
         ws.release(a16)

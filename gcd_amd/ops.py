@@ -134,7 +134,7 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mod
          rows_per_alpha: int = 1, r1_blend: bool = False, conv=None,
          alg_flops_scale: float = 1.0, ln=None, colstats=None, probe_colstats: bool = False,
          out_blocked: bool = False, a_blocked: bool = False, operand_bf16: bool = False,
-         workspace: Optional[torch.Tensor] = None):
+         workspace: Optional[torch.Tensor] = None, sched: int = 0):
     """out = epilogue(A @ W^T); see gcd_gemm_desc in include/gcd_amd.h.
 
     conv: dict(Cin, Hi, Wi, Ho, Wo, stride, upsample) for GEMM_CONV3X3 or dict(Cin, T, HW) for
@@ -142,6 +142,7 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mod
     colstats: optional fp32 [2 * M / 64, N] that receives the per-64-row column sums / sums of squares
     of the fp32 output (gcd_gemm_desc.colstats) for `groupnorm_stats_from_colsums`.
     probe_colstats: do not launch; return whether `colstats` would be honoured for this call.
+    sched: gcd_gemm_desc.sched (bit 0: walk the tiles from the end of the output; results unchanged).
     """
     _need_gpu(a16, w16, out)
     want = torch.bfloat16 if operand_bf16 else torch.float16
@@ -171,6 +172,7 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mod
         d.frame_alpha, d.rows_per_alpha, d.r1_blend = frame_alpha.data_ptr(), rows_per_alpha, int(r1_blend)
     d.out_kind = out_kind
     d.out_blocked, d.a_blocked, d.operand_bf16 = int(out_blocked), int(a_blocked), int(operand_bf16)
+    d.sched = int(sched)
     if ln is not None:
         # fused LayerNorm of the output rows: dict(gamma, beta, out16[, eps, addvec, rows_per_vec, sum_out])
         _need_gpu(ln["gamma"], ln["beta"], ln["out16"], ln.get("addvec"), ln.get("sum_out"))
@@ -271,28 +273,32 @@ def groupnorm_stats_from_colsums(cs1, C1: int, cs2, C2: int, M: int, rows_per_in
 
 
 def groupnorm_apply(x1, x2, rows_per_inst: int, stats, gamma, beta, silu: bool, y16, raw16=None,
-                    reverse: bool = False):
+                    reverse: bool = False, order: Optional[int] = None):
+    """order: walk order of the row blocks (0..3, see gcd_groupnorm_apply in gcd_amd.h); `reverse` = order 1."""
     _need_gpu(x1, x2, stats, gamma, beta, y16, raw16)
+    if order is None:
+        order = 1 if reverse else 0
+    assert 0 <= order <= 3
     M, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[1]
     check(_lib.load().gcd_groupnorm_apply(x1.data_ptr(), _ld(x1), C1, _p(x2),
                                           0 if x2 is None else _ld(x2), C2, M, rows_per_inst,
                                           stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                          int(silu) | (2 if reverse else 0), y16.data_ptr(), _ld(y16), _p(raw16),
+                                          int(silu) | (order << 1), y16.data_ptr(), _ld(y16), _p(raw16),
                                           0 if raw16 is None else _ld(raw16), _stream()),
           "gcd_groupnorm_apply")
     return y16
 
 
 def layernorm(x, gamma, beta, y16, *, eps: float = 1e-5, addvec=None, rows_per_vec: int = 1,
-              sum_out=None):
+              sum_out=None, order: int = 0):
     _need_gpu(x, gamma, beta, y16, addvec, sum_out)
     M, Cc = x.shape
     check(_lib.load().gcd_layernorm_f16(x.data_ptr(), _ld(x), M, Cc, gamma.data_ptr(),
                                         beta.data_ptr(), eps, _p(addvec),
                                         0 if addvec is None else _ld(addvec), rows_per_vec,
                                         _p(sum_out), 0 if sum_out is None else _ld(sum_out),
-                                        y16.data_ptr(), _ld(y16), _stream()), "gcd_layernorm_f16")
+                                        y16.data_ptr(), _ld(y16), order, _stream()), "gcd_layernorm_f16")
     return y16
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GCD_AMD_ABI_VERSION 5
+#define GCD_AMD_ABI_VERSION 6
 
 /* ---- library ------------------------------------------------------------------------------ */
 int gcd_abi_version(void);
@@ -46,7 +46,8 @@ int gcd_device_info(int device, char* name, int cap, int* num_cus, size_t* hbm_b
  *                       256x160 kernel (gemm_p8x, an experiment that lost its A/B) on the large fp16-output grids;
  *                       11 = like 0 without the halo-panel K loop of the stride-1 3x3 convolutions; 5 / 6 = general kernel, never / always
  *                       64-row tiles; 7 = like 0 (split-K allowed, used by tests); >= 32: ablation builds
- *   GCD_TUNE_ATTN_IMPL: 0 = automatic, other values select spatial-attention kernel variants
+ *   GCD_TUNE_ATTN_IMPL: 0 = automatic, 1..3 select spatial-attention kernel variants, 16 = temporal attention on the
+ *                       16-lanes-per-problem VALU kernel instead of the one-problem-per-wave MFMA kernel
  *   GCD_TUNE_PP_MIN_TILES: automatic GEMM choice takes the ping-pong kernel from this many 256x320 tiles
  *                       (0 = the default, 192; environment GCD_PP_MIN_TILES)                   */
 #define GCD_TUNE_GEMM_IMPL 0
@@ -153,6 +154,13 @@ typedef struct gcd_gemm_desc {
      is exponent range — the fine-tune step's gradient GEMMs without loss scaling — at 8 instead of 11
      significant bits (7x over the 1e-3 inference tolerance, so inference stays fp16). */
   int32_t operand_bf16;
+  /* Scheduling hints (ABI v6; results are bit-identical whatever they say).  bit 0: the tiles are walked from the
+     END of the output — every XCD takes its contiguous share of the tile order back to front — instead of from the
+     start.  A launch that reads what the previous launch wrote finds the END of that tensor in the 256 MB Infinity
+     Cache (the start has been evicted by the rest): walking in the opposite direction of the producer turns part of
+     the consumer's HBM reads into cache hits.  Honoured by the 8-phase 256 x 320 kernel without split-K, ignored
+     elsewhere.                                                                                                    */
+  int32_t sched;
 } gcd_gemm_desc;
 
 /* Replaces torch.nn.Linear / Conv2d / Conv3d forward on the hot path:
@@ -196,20 +204,22 @@ int gcd_groupnorm_stats(const float* x1, int64_t ld1, int C1, const float* x2, i
 int gcd_groupnorm_stats_from_colsums(const float* cs1, int C1, const float* cs2, int C2, int64_t M,
                                      int64_t rows_per_inst, float eps, float* stats, void* stream);
 /* y16 = [silu]((x - mean) * rstd * gamma + beta) as fp16 [M, C1+C2]; raw16 (optional) = fp16(x).
- * silu: bit 0 = apply SiLU; bit 1 = walk the rows from the END of the tensor (pure scheduling: when
- * the tensor was just written front to back by a GEMM and not read since, its tail is what the
- * 256 MB Infinity Cache still holds).                                                              */
+ * silu: bit 0 = apply SiLU; bits 1-2 = walk order of the row blocks (pure scheduling, cf. gcd_gemm_desc.sched: what
+ * the previous launch wrote LAST is what the 256 MB Infinity Cache still holds): 0 front to back, 1 back to front,
+ * 2 / 3 the tensor as eight contiguous regions walked concurrently — the order in which a persistent GEMM's eight XCD
+ * shares are written — every region back to front (2) / front to back (3).                          */
 int gcd_groupnorm_apply(const float* x1, int64_t ld1, int C1, const float* x2, int64_t ld2, int C2,
                         int64_t M, int64_t rows_per_inst, const float* stats, const float* gamma,
                         const float* beta, int silu, void* y16, int64_t ldy, void* raw16,
                         int64_t ldraw, void* stream);
 /* LayerNorm over C of (x + addvec[m / rows_per_vec]) -> fp16; optionally writes the fp32 sum back
  * (x_mix = x + time_pos_emb, video_attention.py:283-284).  Replaces nn.LayerNorm at
- * attention.py:519-521 and video_attention.py:50,90-93.                                         */
+ * attention.py:519-521 and video_attention.py:50,90-93.  order: walk order of the row blocks, 0..3 as
+ * gcd_groupnorm_apply's (ABI v6).                                                                */
 int gcd_layernorm_f16(const float* x, int64_t ldx, int64_t M, int C, const float* gamma,
                       const float* beta, float eps, const float* addvec, int64_t ld_addvec,
                       int rows_per_vec, float* sum_out, int64_t ld_sum, void* y16, int64_t ldy,
-                      void* stream);
+                      int order, void* stream);
 
 /* ---- attention ------------------------------------------------------------------------------ */
 /* vt[((f*heads+h)*64 + d) * S_pad + p(s)] = qkv[(f*S+s)*ld + 2C + h*64 + d], zero padded to S_pad;
@@ -306,12 +316,16 @@ int gcd_col2im_t3_f32(const float* dcol, float* dx, int64_t lddx, int64_t M, int
  * bias gradients (one block) and the gradients of per-frame epilogue vectors (emb_layers output).    */
 int gcd_rowblock_sum_f32(const float* x, int64_t ldx, int64_t M, int N, int64_t rows_per_block,
                          float* out_zeroed, void* stream);
-/* GroupNorm(32) [+SiLU] backward: x, dy, dx fp32 [M, C]; stats from gcd_groupnorm_stats; AB_zeroed:
- * ninst*C*2 doubles that receive per (instance, channel) sum(dz), sum(dz*xhat) — dbeta / dgamma are
- * their sums over instances.  Replaces autograd of util.py:259-276 + SiLU.                           */
+/* GroupNorm(32) [+SiLU] backward: x, dy, dx fp32 [M, C]; stats from gcd_groupnorm_stats; AB: ninst*C*2
+ * doubles that RECEIVE per (instance, channel) sum(dz), sum(dz*xhat) — dbeta / dgamma are their sums over
+ * instances (no pre-zeroing: ABI v6 replaced the atomics of the reduction pass by per-chunk partial sums in
+ * `scratch`, >= gcd_groupnorm_bwd_scratch_floats(C, M, rows_per_inst) floats, 16-byte aligned, folded in
+ * fp64 by a second launch).  Replaces autograd of util.py:259-276 + SiLU.                            */
+int64_t gcd_groupnorm_bwd_scratch_floats(int C, int64_t M, int64_t rows_per_inst);
 int gcd_groupnorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int C, int64_t M,
                       int64_t rows_per_inst, const float* stats, const float* gamma, const float* beta,
-                      int silu, double* AB_zeroed, float* dx, int64_t lddx, void* stream);
+                      int silu, double* AB, float* scratch, int64_t scratch_floats, float* dx, int64_t lddx,
+                      void* stream);
 /* LayerNorm backward (rows of C <= 1280): dx, and dgamma / dbeta accumulated into zeroed [C] buffers. */
 int gcd_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t M, int C,
                       const float* gamma, float eps, float* dx, int64_t lddx, float* dgamma_zeroed,

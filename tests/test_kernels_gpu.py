@@ -680,6 +680,107 @@ def test_layernorm(gpu, M, C):
     assert rel_l2(y.float(), F.layer_norm(x, (C,), gamma, beta, 1e-5)) < TOL_F16
 
 
+# ------------------------------------------------------------------------- walk orders (scheduling only)
+@pytest.mark.parametrize("M,C", [(1000, 320), (77, 640), (70, 1280), (16 * 8192 + 37, 320)])
+def test_layernorm_walk_orders_are_bit_identical(gpu, M, C):
+    """gcd_layernorm_f16's `order` (back to front / the GEMM's eight-region orders) is scheduling only: every order
+    writes exactly what order 0 writes — ragged row counts, fewer row blocks than regions, the grid-stride tail."""
+    from gcd_amd import ops
+    g = _gen(91)
+    x = (torch.randn(M, C, generator=g) * 2 + 0.5).to(gpu)
+    gamma, beta = torch.randn(C, generator=g).to(gpu), torch.randn(C, generator=g).to(gpu)
+    add = torch.randn((M + 9) // 10, C, generator=g).to(gpu)
+    outs = []
+    for order in range(4):
+        y = torch.full((M, C), float("nan"), dtype=torch.float16, device=gpu)
+        s = torch.full((M, C), float("nan"), device=gpu)
+        ops.layernorm(x, gamma, beta, y, addvec=add, rows_per_vec=10, sum_out=s, order=order)
+        torch.cuda.synchronize()
+        outs.append((y.cpu(), s.cpu()))
+    assert not torch.isnan(outs[0][0].float()).any() and not torch.isnan(outs[0][1]).any()
+    for order in range(1, 4):
+        assert torch.equal(outs[order][0], outs[0][0]) and torch.equal(outs[order][1], outs[0][1]), order
+
+
+@pytest.mark.parametrize("frames,HW,C1,C2", [(4, 100, 320, 0), (3, 64, 640, 320), (28, 256, 320, 0), (1, 40, 64, 0)])
+def test_groupnorm_apply_walk_orders_are_bit_identical(gpu, frames, HW, C1, C2):
+    from gcd_amd import ops
+    g = _gen(92)
+    C = C1 + C2
+    tok = torch.randn(frames * HW, C, generator=g) * 3 + 1.5
+    x1 = tok[:, :C1].contiguous().to(gpu)
+    x2 = tok[:, C1:].contiguous().to(gpu) if C2 else None
+    gamma, beta = torch.randn(C, generator=g).to(gpu), torch.randn(C, generator=g).to(gpu)
+    nch = ops.gn_nchunks(HW)
+    partial = torch.empty(frames * nch * 64, dtype=torch.float64, device=gpu)
+    stats = torch.empty(frames * 64, device=gpu)
+    ops.groupnorm_stats(x1, x2, HW, 1e-5, partial, stats, nch)
+    outs = []
+    for order in range(4):
+        y = torch.full((frames * HW, C), float("nan"), dtype=torch.float16, device=gpu)
+        raw = torch.full((frames * HW, C), float("nan"), dtype=torch.float16, device=gpu)
+        ops.groupnorm_apply(x1, x2, HW, stats, gamma, beta, True, y, raw, order=order)
+        torch.cuda.synchronize()
+        outs.append((y.cpu(), raw.cpu()))
+    assert not torch.isnan(outs[0][0].float()).any() and not torch.isnan(outs[0][1].float()).any()
+    for order in range(1, 4):
+        assert torch.equal(outs[order][0], outs[0][0]) and torch.equal(outs[order][1], outs[0][1]), order
+
+
+@pytest.mark.parametrize("case", ["plain_persistent", "plain_few_tiles", "geglu", "conv_halo", "conv3x3", "temporal"])
+def test_gemm_reverse_tile_walk_is_bit_identical(gpu, case):
+    """gcd_gemm_desc.sched bit 0 (every XCD walks its share of the tiles from the end) changes the order in which the
+    tiles are computed, nothing else: persistent and one-tile-per-workgroup grids, ragged edges, tile counts that do
+    not divide by 8, the halo-panel / tap-walking / temporal A paths and the in-place residual."""
+    from gcd_amd import ops, packing
+    ops.tune_set(ops.TUNE_GEMM_IMPL, 2)
+    try:
+        g = _gen(93)
+
+        def run(sched):
+            gg = _gen(94)
+            if case in ("plain_persistent", "plain_few_tiles", "geglu"):
+                M, N, K = {"plain_persistent": (256 * 67 + 100, 320 * 5 + 64, 128), "plain_few_tiles": (256 * 5, 640, 320),
+                           "geglu": (256 * 70, 1280, 64)}[case]
+                a = torch.randn(M, K, generator=gg).half().to(gpu)
+                w = (torch.randn(N, K, generator=gg) / math.sqrt(K)).half()
+                bias = torch.randn(N, generator=gg)
+                if case == "geglu":
+                    wp, bp = packing.pack_geglu(w.float(), bias)
+                    out = torch.full((M, N // 2), float("nan"), dtype=torch.float16, device=gpu)
+                    ops.gemm(a, wp.to(gpu), out, M=M, bias=bp.to(gpu), out_kind=ops.OUT_GEGLU, sched=sched)
+                else:
+                    out = torch.randn(M, N, generator=gg).to(gpu)       # residual, updated in place
+                    ops.gemm(a, w.to(gpu), out, M=M, bias=bias.to(gpu), r1=out, sched=sched)
+                return out
+            if case in ("conv_halo", "conv3x3"):
+                frames, H, W, Cin, Cout = (9, 4, 64, 64, 320) if case == "conv_halo" else (28, 24, 32, 128, 320)
+                x = torch.randn(frames, Cin, H, W, generator=gg)
+                w = torch.randn(Cout, Cin, 3, 3, generator=gg) / math.sqrt(9 * Cin)
+                M = frames * H * W
+                a = x.permute(0, 2, 3, 1).reshape(M, Cin).contiguous().half().to(gpu)
+                out = torch.full((M, Cout), float("nan"), device=gpu)
+                ops.gemm(a, packing.pack_conv3x3(w).to(gpu), out, M=M, mode=ops.GEMM_CONV3X3, sched=sched,
+                         bias=torch.randn(Cout, generator=gg).to(gpu),
+                         conv=dict(Cin=Cin, Hi=H, Wi=W, Ho=H, Wo=W, stride=1, upsample=0))
+                return out
+            clips, T, HW, Cc = 2, 14, 700, 128
+            M = clips * T * HW
+            a = torch.randn(M, Cc, generator=gg).half().to(gpu)
+            w = torch.randn(320, Cc, 3, 1, 1, generator=gg) / math.sqrt(3 * Cc)
+            out = torch.full((M, 320), float("nan"), device=gpu)
+            ops.gemm(a, packing.pack_conv_t3(w).to(gpu), out, M=M, mode=ops.GEMM_TEMPORAL3, sched=sched,
+                     conv=dict(Cin=Cc, T=T, HW=HW))
+            return out
+
+        fwd, rev = run(0), run(1)
+        torch.cuda.synchronize()
+        assert not torch.isnan(fwd.float()).any()
+        assert torch.equal(fwd, rev)
+    finally:
+        ops.tune_set(ops.TUNE_GEMM_IMPL, 0)
+
+
 # ------------------------------------------------------------------------------------- attention
 @pytest.fixture(params=[0, 1, 2, 3], ids=["attn-auto", "attn-q32", "attn-q64", "attn-q64p"])
 def attn_impl(request, gpu):
@@ -765,10 +866,15 @@ def test_attention_spatial_reference_shift(gpu, attn_impl):
     assert e < 2e-3, f"reference-shift attention: rel-L2 {e:.3e}"
 
 
+@pytest.mark.parametrize("kernel", ["mfma", "valu"])
 @pytest.mark.parametrize("clips,T,HW,heads", [(2, 14, 10, 3), (1, 4, 33, 1), (2, 16, 7, 5),
-                                              (2, 14, 64, 20)])
-def test_attention_temporal(gpu, clips, T, HW, heads):
+                                              (2, 14, 64, 20), (1, 1, 5, 2), (2, 14, 1500, 5)])
+def test_attention_temporal(gpu, clips, T, HW, heads, kernel):
+    """Both kernels of gcd_attn_temporal_f16: one problem per wave on the matrix pipe (the default) and the
+    16-lanes-per-problem VALU kernel (GCD_TUNE_ATTN_IMPL = 16); the last shape has more problems than resident waves
+    (the mixed-radix problem walk wraps clips, pixels and heads)."""
     from gcd_amd import ops
+    ops.tune_set(ops.TUNE_ATTN_IMPL, 16 if kernel == "valu" else 0)
     g = _gen(11)
     C = heads * 64
     M = clips * T * HW
@@ -777,10 +883,13 @@ def test_attention_temporal(gpu, clips, T, HW, heads):
     ref = F.scaled_dot_product_attention(q.double(), k.double(), v.double())   # b s h t d
     ref = ref.permute(0, 3, 1, 2, 4).reshape(M, C).float()
     out = torch.empty(M, C, dtype=torch.float16, device=gpu)
-    ops.attn_temporal(qkv.half().to(gpu), out, clips, T, HW, heads)
-    torch.cuda.synchronize()
+    try:
+        ops.attn_temporal(qkv.half().to(gpu), out, clips, T, HW, heads)
+        torch.cuda.synchronize()
+    finally:
+        ops.tune_set(ops.TUNE_ATTN_IMPL, 0)
     e = rel_l2(out.float(), ref)
-    assert e < TOL_F16, f"temporal attention rel-L2 {e:.3e}"
+    assert e < TOL_F16, f"temporal attention ({kernel}) rel-L2 {e:.3e}"
 
 
 # ----------------------------------------------------------------------------------- small pieces

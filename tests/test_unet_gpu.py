@@ -99,6 +99,32 @@ def test_unet_image_only_indicator_and_repeatability(gpu, tiny):
     assert torch.equal(out1, out2), "forward is not bit-reproducible run to run"
 
 
+@pytest.mark.parametrize("force_tiles", [False, True])
+def test_unet_walk_directions_are_bit_identical(gpu, tiny, monkeypatch, force_tiles):
+    """The zig-zag schedule (engine._ZIGZAG: reversed tile walks of the GEMMs, walk orders of LayerNorm / GroupNorm
+    apply) is scheduling only: every mode returns the bits of mode 0 — with the automatic kernel choice and with the
+    256 x 320 tile kernels (the ones that honour gcd_gemm_desc.sched) forced on every GEMM."""
+    from gcd_amd import engine, ops
+    net, sd = tiny
+    T, h, w = 14, 16, 16
+    x, ts, ctx, y, ioi = _unet_inputs(O.TINY, T, h, w, 41)
+    args = (x.to(gpu), ts.to(gpu))
+    kw = dict(context=ctx.to(gpu), y=y.to(gpu), num_video_frames=T, image_only_indicator=ioi.to(gpu))
+    if force_tiles:
+        ops.tune_set(ops.TUNE_GEMM_IMPL, 2)
+    try:
+        outs = []
+        for mode in range(5):
+            monkeypatch.setattr(engine, "_ZIGZAG", mode)
+            outs.append(net(*args, **kw).clone())
+        torch.cuda.synchronize()
+    finally:
+        ops.tune_set(ops.TUNE_GEMM_IMPL, 0)
+    assert torch.isfinite(outs[0]).all()
+    for mode in range(1, 5):
+        assert torch.equal(outs[mode], outs[0]), f"GCD_ZIGZAG={mode} changed the result"
+
+
 def test_cross_attention_cache_survives_address_reuse(gpu, tiny):
     """The collapsed cross-attention vectors are cached per context TENSOR OBJECT.  A new clip's
     context that the allocator places at the freed address of the previous one (same shape, same
