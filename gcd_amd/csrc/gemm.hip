@@ -456,7 +456,7 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
   if (impl != 1 && impl != 5 && impl != 6 && gcd_gemm_pp_supported(k, d->mode)) {
     const int64_t tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 319) / 320);
     int min_tiles = gcd_tune_get(GCD_TUNE_PP_MIN_TILES);
-    if (min_tiles <= 0) min_tiles = 192;
+    if (min_tiles <= 0) min_tiles = (d->sched & 2) ? 128 : 192;   // sched bit 1: the caller's shapes pay from 128 tiles
     use_pp = (impl >= 2 && impl != 7) || ((impl == 0 || impl == 7) && tiles >= min_tiles && d->N >= 160);
     // K (or the channels per tap) a multiple of 32 but not of 64: only the ping-pong kernel's 32-deep
     // sub-tiles can walk it
@@ -517,10 +517,11 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
       gcd_gemm_pp_supported(k, d->mode) && d->N >= 160 && d->N % 4 == 0) {
     const int64_t tiles = (int64_t)((d->M + 255) / 256) * ((d->N + 319) / 320);
     int splitk = (int)(256 / tiles);
-    if (tiles <= 32 && d->K >= 4096) {
+    if (tiles <= 32 && d->K >= 4096 && (d->sched & 2)) {
       // a handful of tiles and a very long K: the weight gradients of the fine-tune step (dW = dY^T X, the
       // contraction runs over the tokens: K >= 43 008).  Up to 32 K slices of at least 640, as many as the scratch
-      // holds.  (K >= 4096 keeps the inference path's tiny-M Linears — K = 320 .. 1280 — on their round-2 kernels.)
+      // holds.  Only for callers that ask for it (gcd_gemm_desc.sched bit 1, set by the fine-tune step's GEMMs): the
+      // sampler's few-tile launches keep the 2-4-way split they were measured with.
       if (splitk > 32) splitk = 32;
       while (splitk > 1 && (d->K / splitk < 640 || d->workspace_bytes < (int64_t)splitk * d->M * d->N * 4)) --splitk;
       if (splitk >= 2 && ((uintptr_t)d->workspace & 15) == 0)
@@ -554,7 +555,7 @@ extern "C" int gcd_gemm_colstats_supported(const gcd_gemm_desc* d) {
   if (impl == 1 || impl == 5 || impl == 6) return 0;          // general kernel forced
   const int64_t tiles = (int64_t)(d->M / 256) * (d->N / 320);
   int min_tiles = gcd_tune_get(GCD_TUNE_PP_MIN_TILES);
-  if (min_tiles <= 0) min_tiles = 192;
+  if (min_tiles <= 0) min_tiles = (d->sched & 2) ? 128 : 192;
   if ((impl == 0 || impl == 7) && tiles < min_tiles) return 0;      // automatic choice: general kernel / split-K
   return 1;
 }

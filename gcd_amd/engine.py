@@ -42,7 +42,10 @@ _GN_REVERSE = os.environ.get("GCD_GN_REVERSE", "1") != "0"   # A/B switch (see o
 #      contiguous shares walked concurrently); the attention cores count as front to back
 #   2  as 1 with whole-tensor orders for the norms        3  as 0 with the region order for that GroupNorm
 #   4  as 0 plus every LayerNorm back to front (region order)
-_ZIGZAG = int(os.environ.get("GCD_ZIGZAG", "0"))
+# Measured on one box, interleaved (profiles/r04m_ab_sweep.txt, r04n_ab_sweep.txt): 0: 102.09 / 100.90 ms per step,
+# 1: 101.84, 2: 101.76 / 100.57, 3: 101.97, 4: 102.04 — 2 is the default (-0.3 ms; the cache keeps less of a producer's
+# tail than its size suggests, the rest of the step's traffic flows through it too).
+_ZIGZAG = int(os.environ.get("GCD_ZIGZAG", "2"))
 _ITEMSIZE = {torch.float16: 2, torch.float32: 4, torch.float64: 8, torch.uint8: 1}
 
 

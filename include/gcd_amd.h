@@ -159,7 +159,10 @@ typedef struct gcd_gemm_desc {
      start.  A launch that reads what the previous launch wrote finds the END of that tensor in the 256 MB Infinity
      Cache (the start has been evicted by the rest): walking in the opposite direction of the producer turns part of
      the consumer's HBM reads into cache hits.  Honoured by the 8-phase 256 x 320 kernel without split-K, ignored
-     elsewhere.                                                                                                    */
+     elsewhere.  bit 1: the automatic kernel choice takes the 256 x 320 tile kernels from 128 tiles instead of 192
+     (GCD_TUNE_PP_MIN_TILES unset): the fine-tune step's GEMMs at 32 x 48 latents, where the 84-190-tile shapes of
+     the middle levels run 3 % of the step faster there (profiles/r04n_train_ab.txt); the sampler's shapes at
+     72 x 128 were tuned at 192.                                                                                   */
   int32_t sched;
 } gcd_gemm_desc;
 
