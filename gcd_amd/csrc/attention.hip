@@ -1071,6 +1071,10 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
 // ------------------------------------------------------------------------------------------------
 #define TM_ROW 144   // bytes per V row in LDS: 128 + 16 pad (the four key quads of a ds_read_u16 land 16 banks apart)
 
+// PF: problems of prefetch (the loads of problem p + PF are issued before the arithmetic of problem p).  Measured and
+// not used: PF = 2 (101.19 vs 101.16 ms per step, profiles/r04p_ab_sweep_nontemporal.txt) and non-temporal loads / stores
+// (+0.6 ms per step, profiles/r04q_*: the q|k|v tensor was just written by the GEMM before and partly sits in the caches).
+template <int PF>
 __global__ __launch_bounds__(256) void attn_temporal_mfma_kernel(const f16* __restrict__ qkv, int64_t ld,
                                                                  f16* __restrict__ out, int64_t ldo,
                                                                  int64_t nprob, int T, int HW, int heads) {
@@ -1099,7 +1103,7 @@ __global__ __launch_bounds__(256) void attn_temporal_mfma_kernel(const f16* __re
     b += db + c;
   };
 
-  f16x8 kf[2], qf[2], vf[2];
+  f16x8 kf[PF][2], qf[PF][2], vf[PF][2];   // slot 0 = the current problem, slot j = j problems ahead
   auto load = [&](int h, int s2, int b, f16x8 (&kk)[2], f16x8 (&qq)[2], f16x8 (&vv)[2]) {
     const int64_t row = (int64_t)b * T * HW + s2 + frow;
     const f16* src = lane_base + row * ld + h * 64;
@@ -1110,21 +1114,29 @@ __global__ __launch_bounds__(256) void attn_temporal_mfma_kernel(const f16* __re
       vv[k2] = *(const f16x8*)(src + 2 * C + 32 * k2);
     }
   };
-  load(ph, ps, pb, kf, qf, vf);
+  // (fh, fs, fb): the problem PF ahead of the current one — the next to load
+  int fh = ph, fs = ps, fb = pb;
+#pragma unroll
+  for (int j = 0; j < PF; ++j) {
+    if ((int64_t)pid0 + (int64_t)j * nwaves < nprob) load(fh, fs, fb, kf[j], qf[j], vf[j]);
+    advance(fh, fs, fb);
+  }
   const float cs = 0.125f * 1.4426950408889634f;   // 1 / sqrt(64) in exp2 units
   for (int64_t pid = pid0; pid < nprob; pid += nwaves) {
     f16x8 kn[2], qn[2], vn[2];
-    const bool more = pid + nwaves < nprob;
-    int nh = ph, ns = ps, nb = pb;
-    advance(nh, ns, nb);
-    if (more) load(nh, ns, nb, kn, qn, vn);
+    const bool more = pid + (int64_t)PF * nwaves < nprob;
+    if (more) load(fh, fs, fb, kn, qn, vn);
+    advance(fh, fs, fb);
+    f16x8 (&kc)[2] = kf[0];
+    f16x8 (&qc)[2] = qf[0];
+    f16x8 (&vc)[2] = vf[0];
     // ---- V rows -> the wave's LDS tile (row = frame, 128 B + pad) ----
-    *(f16x8*)(vs + r15 * TM_ROW + 16 * q) = vf[0];
-    *(f16x8*)(vs + r15 * TM_ROW + 64 + 16 * q) = vf[1];
+    *(f16x8*)(vs + r15 * TM_ROW + 16 * q) = vc[0];
+    *(f16x8*)(vs + r15 * TM_ROW + 64 + 16 * q) = vc[1];
     // ---- S^T = K Q^T ----
     f32x4 st = {0.f, 0.f, 0.f, 0.f};
-    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[0], qf[0], st, 0, 0, 0);
-    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[1], qf[1], st, 0, 0, 0);
+    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0], qc[0], st, 0, 0, 0);
+    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[1], qc[1], st, 0, 0, 0);
     // ---- softmax over the keys 4 q + e of query r15 ----
     float sc[4];
     float mx = -INFINITY;
@@ -1176,15 +1188,22 @@ __global__ __launch_bounds__(256) void attn_temporal_mfma_kernel(const f16* __re
         *(f16x4*)(dst + 16 * b) = ov;
       }
     }
-    ph = nh;
-    ps = ns;
-    pb = nb;
+    advance(ph, ps, pb);
+    // rotate the slots: j + 1 -> j, the fresh loads -> PF - 1
+#pragma unroll
+    for (int j = 0; j + 1 < PF; ++j)
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        kf[j][k2] = kf[j + 1][k2];
+        qf[j][k2] = qf[j + 1][k2];
+        vf[j][k2] = vf[j + 1][k2];
+      }
     if (more) {
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
-        kf[k2] = kn[k2];
-        qf[k2] = qn[k2];
-        vf[k2] = vn[k2];
+        kf[PF - 1][k2] = kn[k2];
+        qf[PF - 1][k2] = qn[k2];
+        vf[PF - 1][k2] = vn[k2];
       }
     }
   }
@@ -1203,7 +1222,7 @@ extern "C" int gcd_attn_temporal_f16(const void* qkv, int64_t ld, void* out, int
     // GCD_TUNE_ATTN_IMPL = 16 keeps the 16-lanes-per-problem VALU kernel below (A/B, tests).
     int64_t mblocks = (nprob + 3) / 4;
     if (mblocks > 1792) mblocks = 1792;
-    hipLaunchKernelGGL(attn_temporal_mfma_kernel, dim3((unsigned)mblocks), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(attn_temporal_mfma_kernel<1>, dim3((unsigned)mblocks), dim3(256), 0, (hipStream_t)stream,
                        (const f16*)qkv, ld, (f16*)out, ldo, nprob, T, HW, heads);
     GCD_CHECK_LAUNCH();
     return 0;

@@ -115,6 +115,9 @@ if __name__ == "__main__":
     elif "--epi-wt" in sys.argv:      # write-through epilogue stores (gemm_common.h, GCD_EPI_WT): A/B library
         mask = int(sys.argv[sys.argv.index("--epi-wt") + 1])
         print(_build_ablation(True, f"wt{mask}", (f"-DGCD_EPI_WT={mask}",)))
+    elif "--epi-nt" in sys.argv:      # non-temporal epilogue stores / residual loads (GCD_EPI_NT): A/B library
+        mask = int(sys.argv[sys.argv.index("--epi-nt") + 1])
+        print(_build_ablation(True, f"nt{mask}", (f"-DGCD_EPI_NT={mask}",)))
     else:
         build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv)
         print(LIB)

@@ -65,17 +65,28 @@ struct GemmK {
 #ifndef GCD_EPI_WT
 #define GCD_EPI_WT 0
 #endif
-template <bool WT, typename V>
+// -DGCD_EPI_NT=mask: the same paths with NON-TEMPORAL stores (bits 1 / 2 / 4 as above) and, bit 8, non-temporal loads of
+// the fp32 residuals (read once per launch) — the hint that moved the LayerNorm / GroupNorm streamers (norm.hip).
+#ifndef GCD_EPI_NT
+#define GCD_EPI_NT 0
+#endif
+template <bool WT, bool NT, typename V>
 __device__ __forceinline__ void gcd_store16(void* ptr, const V& v) {
   static_assert(sizeof(V) == 16, "16-byte vector");
   if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v));
+  else if constexpr (NT) __builtin_nontemporal_store(v, (V*)ptr);
   else *(V*)ptr = v;
 }
-template <bool WT, typename V>
+template <bool WT, bool NT, typename V>
 __device__ __forceinline__ void gcd_store8(void* ptr, const V& v) {
   static_assert(sizeof(V) == 8, "8-byte vector");
   if constexpr (WT) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(ptr), "v"(v));
+  else if constexpr (NT) __builtin_nontemporal_store(v, (V*)ptr);
   else *(V*)ptr = v;
+}
+__device__ __forceinline__ f32x4 gcd_load_res(const float* p) {
+  if constexpr ((GCD_EPI_NT & 8) != 0) return __builtin_nontemporal_load((const f32x4*)p);
+  else return *(const f32x4*)p;
 }
 
 // gemm_pp.hip: the 256 x 320 ping-pong kernel.
@@ -369,8 +380,8 @@ __device__ __forceinline__ void gcd_epi_f32_rows_full(const GemmK& p, ACC& acc, 
     const int i = b >> 1, j = b & 1;
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
-      if (HAS_R1) q1[slot][qq] = *(const f32x4*)(r1p + (4 * j + qq) * s1 + 32 * i);
-      if (HAS_R2) q2[slot][qq] = *(const f32x4*)(r2p + (4 * j + qq) * s2 + 32 * i);
+      if (HAS_R1) q1[slot][qq] = gcd_load_res(r1p + (4 * j + qq) * s1 + 32 * i);
+      if (HAS_R2) q2[slot][qq] = gcd_load_res(r2p + (4 * j + qq) * s2 + 32 * i);
     }
   };
   if (HAS_R1 || HAS_R2) {
@@ -398,9 +409,9 @@ __device__ __forceinline__ void gcd_epi_f32_rows_full(const GemmK& p, ACC& acc, 
         f16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (f16)v[e];
-        gcd_store8<(GCD_EPI_WT & 4) != 0>(op16 + (4 * j + qq) * so + 32 * i, o);
+        gcd_store8<(GCD_EPI_WT & 4) != 0, (GCD_EPI_NT & 4) != 0>(op16 + (4 * j + qq) * so + 32 * i, o);
       } else {
-        gcd_store16<(GCD_EPI_WT & 4) != 0>(op + (4 * j + qq) * so + 32 * i, v);
+        gcd_store16<(GCD_EPI_WT & 4) != 0, (GCD_EPI_NT & 4) != 0>(op + (4 * j + qq) * so + 32 * i, v);
       }
     }
     if ((HAS_R1 || HAS_R2) && b + D < 10) fetch(b + D, b % D);
@@ -450,7 +461,7 @@ __device__ __forceinline__ void gcd_epi_geglu_rows_full(const GemmK& p, ACC& acc
       const int tt = it * 64 + lane;
       const int row = tt / 10, ch = tt - row * 10;
       const f16x8 v = *(const f16x8*)(stage + row * GCD_EPI_ROW_F16 + ch * 16);
-      gcd_store16<(GCD_EPI_WT & 1) != 0>(outp + (int64_t)(32 * j + row) * rs + ch * 8, v);
+      gcd_store16<(GCD_EPI_WT & 1) != 0, (GCD_EPI_NT & 1) != 0>(outp + (int64_t)(32 * j + row) * rs + ch * 8, v);
     }
   }
 }
@@ -471,7 +482,7 @@ __device__ __forceinline__ void gcd_epi_f16_rows_full(const GemmK& p, ACC& acc, 
       const int tt = it * 64 + lane;
       const int row = tt / 20, ch = tt - row * 20;
       const f16x8 v = *(const f16x8*)(stage + row * GCD_EPI_ROW_H160 + ch * 16);
-      gcd_store16<(GCD_EPI_WT & 2) != 0>(outp + (int64_t)row * p.ldo + ch * 8, v);
+      gcd_store16<(GCD_EPI_WT & 2) != 0, (GCD_EPI_NT & 2) != 0>(outp + (int64_t)row * p.ldo + ch * 8, v);
     }
   }
 }

@@ -10,6 +10,9 @@
 //     normalised + SiLU'd, together with an optional raw fp16 copy for the 1x1 skip conv.
 #include "common.h"
 
+int gcd_tune_get(int knob);   // runtime.hip
+#define GCD_STREAM_DEFAULT 3   // set from profiles/r04q_* / r04r_* (same-box sweeps)
+
 // Walk orders of the two big streaming kernels (GroupNorm apply, LayerNorm): position v of the dispatch order -> block
 // of rows.  Pure scheduling (see gcd_gemm_desc.sched in gcd_amd.h): a kernel that reads what the previous launch wrote
 // finds in the 256 MB Infinity Cache what that launch wrote LAST.
@@ -25,6 +28,29 @@ __device__ __forceinline__ int64_t gcd_walk(int64_t v, int64_t nb, int order) {
   const int64_t start = r < rem ? r * (q + 1) : rem * (q + 1) + (r - rem) * q;
   const int64_t len = q + (r < rem ? 1 : 0);
   return order == 2 ? start + len - 1 - pos : start + pos;
+}
+
+// Streaming loads / stores of the two big streamers, optionally non-temporal (GCD_TUNE_STREAM bit 0 loads, bit 1
+// stores; A/B knob): NT = 2 * stores + loads.
+template <int NT>
+__device__ __forceinline__ f32x4 gcd_ld16(const float* p) {
+  if constexpr ((NT & 1) != 0) return __builtin_nontemporal_load((const f32x4*)p);
+  else return *(const f32x4*)p;
+}
+template <int NT, typename V, typename T>
+__device__ __forceinline__ void gcd_st(T* p, const V v) {
+  if constexpr ((NT & 2) != 0) __builtin_nontemporal_store(v, (V*)p);
+  else *(V*)p = v;
+}
+// Host: the NT mode of a launch that streams `bytes` (fp32 in + fp16 out).  GCD_TUNE_STREAM: bits 0-1 the mode
+// (0 = the default, see below; 4 = plain loads and stores everywhere), bits 4-7 a size threshold in units of 100 MB
+// below which a launch keeps plain accesses (its tensors fit the caches and the next launch reads them from there).
+static int gcd_stream_nt(int64_t bytes) {
+  int knob = gcd_tune_get(GCD_TUNE_STREAM);
+  if (knob == 0) knob = GCD_STREAM_DEFAULT;
+  if (knob & 4) return 0;
+  const int64_t thresh = (int64_t)((knob >> 4) & 15) * 100 * 1000 * 1000;
+  return bytes >= thresh ? (knob & 3) : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -244,6 +270,7 @@ extern "C" int gcd_groupnorm_stats_from_colsums(const float* cs1, int C1, const 
 // GroupNorm apply (+SiLU) -> fp16, optional raw fp16 copy.
 // grid = (row chunks, ninst); block 256.  Per-channel scale/shift are built once per block in LDS.
 // ------------------------------------------------------------------------------------------------
+template <int NT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(
     const float* __restrict__ x1, int64_t ld1, int C1, const float* __restrict__ x2, int64_t ld2,
     int C2, int64_t rows_per_inst, int rows_per_chunk, const float* __restrict__ stats,
@@ -293,12 +320,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
       if (silu) u = silu_f(u);
       o[e] = (f16)u;
     }
-    *(f16x4*)(y + (base + rr) * ldy + c) = o;
+    gcd_st<NT, f16x4>(y + (base + rr) * ldy + c, o);
     if (raw) {
       f16x4 q;
 #pragma unroll
       for (int e = 0; e < 4; ++e) q[e] = (f16)v[e];
-      *(f16x4*)(raw + (base + rr) * ldraw + c) = q;
+      gcd_st<NT, f16x4>(raw + (base + rr) * ldraw + c, q);
     }
   };
   // four vectors (64 B) in flight per thread
@@ -310,7 +337,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
     for (int k = 0; k < 4; ++k) {
       rr[k] = r;
       cc[k] = c4 * 4;
-      v[k] = *(const f32x4*)src_of(r, c4 * 4);
+      v[k] = gcd_ld16<NT>(src_of(r, c4 * 4));
       r += qs;
       c4 += rs;
       if (c4 >= cv4) {
@@ -322,7 +349,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
     for (int k = 0; k < 4; ++k) emit(v[k], rr[k], cc[k]);
   }
   for (; idx < total; idx += 256) {
-    const f32x4 v = *(const f32x4*)src_of(r, c4 * 4);
+    const f32x4 v = gcd_ld16<NT>(src_of(r, c4 * 4));
     emit(v, r, c4 * 4);
     r += qs;
     c4 += rs;
@@ -360,9 +387,17 @@ extern "C" int gcd_groupnorm_apply(const float* x1, int64_t ld1, int C1, const f
     rpc = (int)((rows_per_inst + nchunks - 1) / nchunks);
     nchunks = (rows_per_inst + rpc - 1) / rpc;
   }
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)nchunks, ninst), dim3(256), C * 8,
-                     (hipStream_t)stream, x1, ld1, C1, x2, ld2, C2, rows_per_inst, rpc, stats, gamma,
-                     beta, silu, (f16*)y16, ldy, (f16*)raw16, ldraw);
+#define GCD_GN_APPLY(NT)                                                                                  \
+  hipLaunchKernelGGL(gn_apply_kernel<NT>, dim3((unsigned)nchunks, ninst), dim3(256), C * 8, (hipStream_t)stream, \
+                     x1, ld1, C1, x2, ld2, C2, rows_per_inst, rpc, stats, gamma, beta, silu, (f16*)y16, ldy,     \
+                     (f16*)raw16, ldraw)
+  switch (gcd_stream_nt((int64_t)M * C * 6)) {
+    case 1: GCD_GN_APPLY(1); break;
+    case 2: GCD_GN_APPLY(2); break;
+    case 3: GCD_GN_APPLY(3); break;
+    default: GCD_GN_APPLY(0); break;
+  }
+#undef GCD_GN_APPLY
   GCD_CHECK_LAUNCH();
   return 0;
 }
@@ -439,7 +474,7 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-template <int NV, int LPR>  // float4 vectors per lane, lanes per row: C = 4 * NV * LPR
+template <int NV, int LPR, int NT>  // float4 vectors per lane, lanes per row: C = 4 * NV * LPR; NT: gcd_ld16 / gcd_st
 __global__ __launch_bounds__(256) void layernorm16_kernel(
     const float* __restrict__ x, int64_t ldx, int64_t M, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, const float* __restrict__ addvec, int64_t ld_addvec,
@@ -460,7 +495,7 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(
     const float* row = x + m * ldx + l16 * 4;
     f32x4 v[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = *(const f32x4*)(row + RS * i);
+    for (int i = 0; i < NV; ++i) v[i] = gcd_ld16<NT>(row + RS * i);
     if (addvec) {
       const float* av = addvec + (m / rows_per_vec) * ld_addvec + l16 * 4;
 #pragma unroll
@@ -486,8 +521,8 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(
       f16x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (f16)((v[i][e] - mean) * rstd * g[e] + b[e]);
-      *(f16x4*)(yr + RS * i) = o;
-      if (sum_out) *(f32x4*)(sum_out + m * ld_sum + l16 * 4 + RS * i) = v[i];
+      gcd_st<NT, f16x4>(yr + RS * i, o);
+      if (sum_out) gcd_st<NT, f32x4>(sum_out + m * ld_sum + l16 * 4 + RS * i, v[i]);
     }
   }
 }
@@ -509,12 +544,26 @@ extern "C" int gcd_layernorm_f16(const float* x, int64_t ldx, int64_t M, int C, 
     const int rpb = C == 320 ? 16 : 8;   // rows per 256-thread block
     int64_t blocks16 = (M + rpb - 1) / rpb;
     if (blocks16 > 8192) blocks16 = 8192;
-    if (C == 320)
-      hipLaunchKernelGGL((layernorm16_kernel<5, 16>), dim3((unsigned)blocks16), dim3(256), 0, s, x, ldx, M,
-                         gamma, beta, eps, addvec, ld_addvec, rows_per_vec, sum_out, ld_sum, (f16*)y16, ldy, order);
-    else
-      hipLaunchKernelGGL((layernorm16_kernel<5, 32>), dim3((unsigned)blocks16), dim3(256), 0, s, x, ldx, M,
-                         gamma, beta, eps, addvec, ld_addvec, rows_per_vec, sum_out, ld_sum, (f16*)y16, ldy, order);
+#define GCD_LN16(LPR, NT)                                                                                    \
+  hipLaunchKernelGGL((layernorm16_kernel<5, LPR, NT>), dim3((unsigned)blocks16), dim3(256), 0, s, x, ldx, M, gamma, \
+                     beta, eps, addvec, ld_addvec, rows_per_vec, sum_out, ld_sum, (f16*)y16, ldy, order)
+    const int nt = gcd_stream_nt(M * C * 6);
+    if (C == 320) {
+      switch (nt) {
+        case 1: GCD_LN16(16, 1); break;
+        case 2: GCD_LN16(16, 2); break;
+        case 3: GCD_LN16(16, 3); break;
+        default: GCD_LN16(16, 0); break;
+      }
+    } else {
+      switch (nt) {
+        case 1: GCD_LN16(32, 1); break;
+        case 2: GCD_LN16(32, 2); break;
+        case 3: GCD_LN16(32, 3); break;
+        default: GCD_LN16(32, 0); break;
+      }
+    }
+#undef GCD_LN16
     GCD_CHECK_LAUNCH();
     return 0;
   }

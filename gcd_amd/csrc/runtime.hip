@@ -37,7 +37,7 @@ static bool g_tune_init = false;
 static void tune_init() {
   if (g_tune_init) return;
   g_tune_init = true;
-  static const char* env_names[GCD_TUNE_COUNT] = {"GCD_GEMM_IMPL", "GCD_ATTN_IMPL", "GCD_PP_MIN_TILES"};
+  static const char* env_names[GCD_TUNE_COUNT] = {"GCD_GEMM_IMPL", "GCD_ATTN_IMPL", "GCD_PP_MIN_TILES", "GCD_STREAM"};
   for (int i = 0; i < GCD_TUNE_COUNT; ++i) {
     const char* e = getenv(env_names[i]);
     g_tune[i] = e ? atoi(e) : 0;

@@ -53,7 +53,11 @@ int gcd_device_info(int device, char* name, int cap, int* num_cus, size_t* hbm_b
 #define GCD_TUNE_GEMM_IMPL 0
 #define GCD_TUNE_ATTN_IMPL 1
 #define GCD_TUNE_PP_MIN_TILES 2
-#define GCD_TUNE_COUNT 3
+#define GCD_TUNE_STREAM 3       /* non-temporal accesses of the two big streamers, LayerNorm (C = 320 / 640) and GroupNorm
+                                   apply (environment GCD_STREAM): 0 = the library's default; else bit 0 non-temporal
+                                   loads, bit 1 non-temporal stores, bit 2 (value 4) plain accesses everywhere, bits 4-7 =
+                                   only for launches that stream at least that many hundred MB */
+#define GCD_TUNE_COUNT 4
 int gcd_tune_set(int knob, int value);
 
 /* ---- GEMM family (Linear / Conv2d 3x3 / Conv2d 1x1 / Conv3d (3,1,1) as implicit GEMM) ------ */
