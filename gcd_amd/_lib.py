@@ -115,7 +115,43 @@ SIGNATURES = {
     "gcd_stream_sync": (_i, [_vp]),
 }
 
+# libgcd_amd_train.so (include/gcd_amd_train.h): kernels of the fine-tune step only
+TRAIN_LIB_PATH = _PKG / "libgcd_amd_train.so"
+TRAIN_ABI_VERSION = 1
+TRAIN_SIGNATURES = {
+    "gcd_train_abi_version": (_i, []),
+    "gcd_train_last_error": (C.c_char_p, []),
+    "gcd_wgrad_tr_scratch_floats": (_i64, [_i64, _i, _i]),
+    "gcd_wgrad_tr_f16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _i64, _vp, _i64, _vp]),
+}
+
 _lib = None
+_train = None
+
+
+def load_train() -> C.CDLL:
+    """Load libgcd_amd_train.so (once).  Raises if it has not been built — never falls back."""
+    global _train
+    if _train is not None:
+        return _train
+    if not TRAIN_LIB_PATH.exists():
+        raise GcdError(f"{TRAIN_LIB_PATH} is missing: run `python -m gcd_amd.csrc.build` (needs hipcc)")
+    lib = C.CDLL(str(TRAIN_LIB_PATH))
+    for name, (res, args) in TRAIN_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.gcd_train_abi_version()
+    if v != TRAIN_ABI_VERSION:
+        raise GcdError(f"libgcd_amd_train ABI version {v} != expected {TRAIN_ABI_VERSION}; rebuild the library")
+    _train = lib
+    return lib
+
+
+def check_train(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load_train().gcd_train_last_error().decode(errors="replace")
+        raise GcdError(f"{what or 'libgcd_amd_train call'} failed (status {rc}): {msg}")
 
 
 def load() -> C.CDLL:

@@ -120,6 +120,35 @@ def _t16_padded(x16: torch.Tensor, granule: int = 64) -> torch.Tensor:
 
 
 _FUSE_DY_SUMS = os.environ.get("GCD_TRAIN_FUSE_DY_SUMS", "1") != "0"      # A/B switch
+# Weight gradients dW = dY^T X:  "gemm" = transposed copies of dY and X + the split-K gcd_gemm_f16 (round 3);
+# "tr" = gcd_wgrad_tr_f16 (libgcd_amd_train.so, round 4): both operands stay row-major, transposed on the LDS read.
+# Default "tr": same box, interleaved, forward + backward of the full-width step 0.1806 -> 0.1782 s, gradients equal to
+# 2.7e-6 (profiles/r04w_wgrad_ab.txt); shapes the kernel does not take (N or K not multiples of 8) fall back to "gemm".
+WGRAD_IMPL = os.environ.get("GCD_TRAIN_WGRAD", "tr")
+
+
+def set_wgrad_impl(name: str) -> None:
+    global WGRAD_IMPL
+    if name not in ("gemm", "tr"):
+        raise ValueError("wgrad implementation must be 'gemm' or 'tr'")
+    WGRAD_IMPL = name
+
+
+def _wgrad(dy16: torch.Tensor, x16: torch.Tensor) -> torch.Tensor:
+    """dW [N, K] fp32 = dY^T X for dy16 [M, N], x16 [M, K] (same 16-bit type, rows = tokens)."""
+    M, N = dy16.shape
+    K = x16.shape[1]
+    dw = torch.empty(N, K, dtype=_f32, device=dy16.device)
+    if WGRAD_IMPL == "tr" and N % 8 == 0 and K % 8 == 0 and dy16.stride(1) == 1 and x16.stride(1) == 1 and \
+            dy16.stride(0) % 8 == 0 and x16.stride(0) % 8 == 0 and dy16.data_ptr() % 16 == 0 and x16.data_ptr() % 16 == 0:
+        lib = _lib.load_train()
+        scratch = torch.empty(int(lib.gcd_wgrad_tr_scratch_floats(M, N, K)), dtype=_f32, device=dy16.device)
+        _lib.check_train(lib.gcd_wgrad_tr_f16(dy16.data_ptr(), dy16.stride(0), x16.data_ptr(), x16.stride(0), M, N, K,
+                                              int(dy16.dtype == _bf16), dw.data_ptr(), K, scratch.data_ptr(),
+                                              scratch.numel(), _stream()), "gcd_wgrad_tr_f16")
+        return dw
+    _gemm(_t16_padded(dy16), _t16_padded(x16), dw, M=N)       # split-K over the tokens
+    return dw
 _WS = {}
 
 
@@ -192,9 +221,7 @@ def _grad_contractions(dy32: torch.Tensor, x16: torch.Tensor, w_t16, need_dx: bo
             wtp[:, :N] = wt
             _gemm(dyp, wtp, dx, M=M)
     if need_dw:
-        K = x16.shape[1]
-        dw = torch.empty(N, K, dtype=_f32, device=dev)
-        _gemm(_t16_padded(dy16), _t16_padded(_as_dtype(x16, dt)), dw, M=N)
+        dw = _wgrad(dy16, _as_dtype(x16, dt))
     return dx, dw
 
 
@@ -446,8 +473,7 @@ def _contract_bwd(kind, dy, a16, params, geo, need_da, need_dw, dy16=None, db_pr
                                         geo["stride"], geo["upsample"], 0, _stream()), "gcd_col2im3x3_f32")
             da = dxp[:, :Cin] if cin_p != Cin else dxp
         if need_dw[0]:
-            dwp = torch.empty(cout_p, 9 * cin_p, dtype=_f32, device=dev)
-            _gemm(_t16_padded(dy16), _t16_padded(col), dwp, M=cout_p)       # dW = dY^T col, split-K over the tokens
+            dwp = _wgrad(dy16, col)       # dW = dY^T col [cout_p, 9 * cin_p], contraction over the tokens
             dw = dwp.reshape(cout_p, 3, 3, cin_p).permute(0, 3, 1, 2)[:Cout, :Cin].contiguous()
         return da, [dw, bias_grad(bias, need_dw[1])]
     if kind == "t3":
@@ -466,8 +492,7 @@ def _contract_bwd(kind, dy, a16, params, geo, need_da, need_dw, dy16=None, db_pr
             col = torch.empty(M, 3 * Cc, dtype=dt, device=dev)
             check(lib.gcd_im2col_t3_f16(xg.data_ptr(), _ld(xg), col.data_ptr(), M, Cc, geo["T"], geo["HW"],
                                         _stream()), "gcd_im2col_t3_f16")
-            dwp = torch.empty(Cout, 3 * Cc, dtype=_f32, device=dev)
-            _gemm(_t16_padded(dy16), _t16_padded(col), dwp, M=Cout)
+            dwp = _wgrad(dy16, col)
             dw = dwp.reshape(Cout, 3, Cc).permute(0, 2, 1).reshape(Cout, Cc, 3, 1, 1).contiguous()
         return da, [dw, bias_grad(bias, need_dw[1])]
     raise ValueError(kind)

@@ -21,6 +21,12 @@ STAMP = PKG / ".libgcd_amd.stamp"
 SOURCES = ["runtime.hip", "gemm.hip", "gemm_pp.hip", "gemm_p8.hip", "gemm_p8x.hip", "norm.hip", "attention.hip", "attn_bwd.hip",
            "elementwise.hip", "backward.hip"]
 HEADERS = [CSRC / "common.h", CSRC / "gemm_common.h", ROOT / "include" / "gcd_amd.h"]
+# libgcd_amd_train.so: kernels of the fine-tune step only (include/gcd_amd_train.h).  Its sources are NOT part of
+# `sources_digest()`: they cannot change a kernel the sampler step launches.
+LIB_TRAIN = PKG / "libgcd_amd_train.so"
+STAMP_TRAIN = PKG / ".libgcd_amd_train.stamp"
+TRAIN_SOURCES = ["train_wgrad.hip"]
+TRAIN_HEADERS = [ROOT / "include" / "gcd_amd_train.h"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-ffp-contract=fast"]
@@ -51,6 +57,34 @@ def sources_digest() -> str:
     return h.hexdigest()[:16]
 
 
+def build_train(force: bool = False, verbose: bool = True) -> Path:
+    """gcd_amd/libgcd_amd_train.so (the fine-tune step's own kernels), in-tree like the main library."""
+    h = hashlib.sha256()
+    for p in [CSRC / s for s in TRAIN_SOURCES] + TRAIN_HEADERS:
+        h.update(p.read_bytes())
+    h.update(" ".join(FLAGS).encode())
+    digest = h.hexdigest()
+    if not force and LIB_TRAIN.exists() and STAMP_TRAIN.exists() and STAMP_TRAIN.read_text().strip() == digest:
+        return LIB_TRAIN
+    hipcc = _hipcc()
+    objdir = CSRC / "build"
+    objdir.mkdir(exist_ok=True)
+    objs = []
+    for src in TRAIN_SOURCES:
+        obj = objdir / (src + ".o")
+        cmd = [hipcc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+        if verbose:
+            print("[gcd_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=str(objdir))
+        objs.append(str(obj))
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", str(LIB_TRAIN)]
+    if verbose:
+        print("[gcd_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    STAMP_TRAIN.write_text(digest)
+    return LIB_TRAIN
+
+
 def build(force: bool = False, save_temps: bool = False, verbose: bool = True,
           ablation: bool = False) -> Path:
     """ablation=True builds tools/libgcd_amd_ablate.so instead: the same sources with
@@ -58,6 +92,7 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True,
     (GCD_TUNE_GEMM_IMPL >= 32).  The product library never contains them."""
     if ablation:
         return _build_ablation(verbose)
+    build_train(force=force, verbose=verbose)
     digest = _digest()
     if not force and LIB.exists() and STAMP.exists() and STAMP.read_text().strip() == digest:
         return LIB

@@ -226,6 +226,34 @@ def test_temporal_attention_backward(gpu, clips, T, HW, heads):
     _check("dqkv", qg.grad, qr.grad, 1e-3)      # fp32 backward on fp16-rounded q, k, v
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(4096, 320, 1280), (1000, 208, 336), (2688, 1280, 640), (100, 8, 24)])
+def test_weight_gradient_transposing_read_kernel(gpu, M, N, K, dtype):
+    """gcd_wgrad_tr_f16 (libgcd_amd_train.so): dW = dY^T X with both operands row-major, transposed on the LDS read
+    (ds_read_b64_tr_b16) — against fp32 torch and against the round-3 path (transposed copies + split-K gcd_gemm_f16),
+    ragged tiles, a token count that is not a multiple of the 32-token step, strided operand views."""
+    from gcd_amd import autograd_ops as A
+    dt = torch.float16 if dtype == "fp16" else torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    dyb = (torch.randn(M, N + 8, generator=g) * 0.5).to(dt).to(gpu)
+    xb = torch.randn(M, K + 16, generator=g).to(dt).to(gpu)
+    dy, x = dyb[:, :N], xb[:, 8:8 + K]                       # row strides N + 8 / K + 16, 16-byte aligned starts
+    ref = dy.float().cpu().t() @ x.float().cpu()
+    old = A.WGRAD_IMPL
+    try:
+        A.set_wgrad_impl("tr")
+        dw_tr = A._wgrad(dy, x)
+        A.set_wgrad_impl("gemm")
+        dw_gemm = A._wgrad(dy.contiguous(), x.contiguous()) if K % 16 == 0 and N % 16 == 0 else None
+        torch.cuda.synchronize()
+    finally:
+        A.set_wgrad_impl(old)
+    tol = 1e-4                                               # exact products, fp32 accumulation in both paths
+    assert rel_l2(dw_tr, ref) < tol, rel_l2(dw_tr, ref)
+    if dw_gemm is not None:
+        assert rel_l2(dw_tr, dw_gemm.cpu()) < 2 * tol
+
+
 def test_adam_step_vs_torch(gpu):
     from gcd_amd.training import AdamHIP
     g = _gen(9)

@@ -27,6 +27,20 @@ def test_library_exports_every_declared_symbol():
     assert lib.gcd_abi_version() == _lib.ABI_VERSION == 6
 
 
+def test_train_library_exports_every_declared_symbol():
+    """libgcd_amd_train.so (the fine-tune step's own kernels) against include/gcd_amd_train.h; argument validation is
+    observable without a GPU."""
+    from gcd_amd import _lib
+    header = (ROOT / "include" / "gcd_amd_train.h").read_text()
+    declared = set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(gcd_\w+)\s*\(", header, flags=re.M))
+    assert declared == set(_lib.TRAIN_SIGNATURES), (declared ^ set(_lib.TRAIN_SIGNATURES))
+    lib = _lib.load_train()
+    assert lib.gcd_train_abi_version() == _lib.TRAIN_ABI_VERSION
+    assert lib.gcd_wgrad_tr_scratch_floats(43008, 320, 1280) == 34 * 320 * 1280      # 3 x 10 tiles -> 34 token slices
+    assert lib.gcd_wgrad_tr_f16(16, 320, 16, 1280, 100, 321, 1280, 0, 16, 1280, 16, 1 << 30, None) != 0
+    assert b"multiples of 8" in lib.gcd_train_last_error()
+
+
 def test_gemm_desc_layout_matches_header(tmp_path):
     """ctypes mirror of gcd_gemm_desc has the C struct's offsets and size (checked with gcc)."""
     import shutil
