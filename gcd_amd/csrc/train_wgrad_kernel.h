@@ -1,0 +1,169 @@
+// train_wgrad_kernel.h — the device code of gcd_wgrad_tr_f16 (train_wgrad.hip), in a header of its own so that
+// tools/gemm_tr_probe.cpp compiles and fp64-checks EXACTLY the kernels the library launches.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef short v4s __attribute__((__vector_size__(4 * sizeof(short))));
+#define GCD_AS3 __attribute__((address_space(3)))
+#ifndef GCD_WGRAD_TM_DEFAULT
+#define GCD_WGRAD_TM_DEFAULT 32   // tokens per step the library launches with (train_wgrad.hip)
+#endif
+
+namespace gcd_wgrad {
+
+constexpr int TN = 128, TK = 128;              // output tile
+constexpr int PITCH = TN * 2 + 16;             // bytes per LDS row: 128 16-bit elements + 16 B pad (TN == TK)
+// LDS of a launch with TM tokens per step: [buffer][operand][TM rows]
+constexpr int smem_bytes(int TM) { return 2 * 2 * TM * PITCH; }
+
+// 8 consecutive tokens (rows r0 + 8 g .. + 7 of the step's tile, g = lane >> 4) of column c0 + (lane & 15): two
+// transposing reads of 4 rows each.  Lane i of a 16-lane group supplies the address of row i / 4, columns 4 (i % 4) .. + 3
+// of the 4 x 16 block; it receives column i (profiles/r04_probe_ds_read_tr_b16.txt).
+__device__ __forceinline__ f16x8 frag_tr(const char* tile, int r0, int c0, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const char* p = tile + (r0 + 8 * g + (i >> 2)) * PITCH + (c0 + 4 * (i & 3)) * 2;
+  const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GCD_AS3 v4s*)(p));
+  const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GCD_AS3 v4s*)(p + 4 * PITCH));
+  const f16x4 l4 = __builtin_bit_cast(f16x4, lo), h4 = __builtin_bit_cast(f16x4, hi);
+  return (f16x8){l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+}
+
+// grid (ceil(K / TK), ceil(N / TN), S): workgroup (kt, nt, s) accumulates tokens [s * mper, (s + 1) * mper) into
+// part[s][N][K].  128 x 128 output tile, 4 waves of 64 x 64 (16 accumulators of v_mfma_f32_16x16x32), TM tokens per
+// step (32 or 64: one barrier per 16 / 32 MFMAs of a wave), operands through registers into a double-buffered LDS tile.
+// The 16-bit payload travels as f16x8 bit patterns; BF16 only selects the MFMA.  Dynamic LDS: smem_bytes(TM).
+template <bool BF16, int TM>
+__global__ __launch_bounds__(256) void wgrad_tr_kernel(const f16* __restrict__ dY, int64_t lddy,
+                                                       const f16* __restrict__ X, int64_t ldx,
+                                                       float* __restrict__ part, int64_t M, int N, int K, int64_t mper) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TILE_BYTES = TM * PITCH, NP = TM / 16;     // NP: 16-row staging passes per operand
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int n0 = blockIdx.y * TN, k0 = blockIdx.x * TK;
+  const int64_t m_begin = (int64_t)blockIdx.z * mper;
+  int64_t m_end = m_begin + mper;
+  if (m_end > M) m_end = M;
+  const int nsteps = m_end > m_begin ? (int)((m_end - m_begin + TM - 1) / TM) : 0;
+  const int srow = t >> 4, schunk = t & 15;      // staging: row t / 16 (+ 16 per pass), 16-byte chunk t % 16 of a tile row
+  f16x8 ra[NP], rb[NP];
+  auto gload = [&](int step) {
+#pragma unroll
+    for (int h = 0; h < NP; ++h) {
+      const int64_t m = m_begin + (int64_t)step * TM + srow + 16 * h;
+      const int n = n0 + 8 * schunk, k = k0 + 8 * schunk;
+      const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      ra[h] = (m < m_end && n < N) ? *(const f16x8*)(dY + m * lddy + n) : z;
+      rb[h] = (m < m_end && k < K) ? *(const f16x8*)(X + m * ldx + k) : z;
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* a = smem + buf * 2 * TILE_BYTES;
+    char* b = a + TILE_BYTES;
+#pragma unroll
+    for (int h = 0; h < NP; ++h) {
+      *(f16x8*)(a + (srow + 16 * h) * PITCH + schunk * 16) = ra[h];
+      *(f16x8*)(b + (srow + 16 * h) * PITCH + schunk * 16) = rb[h];
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (nsteps > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    if (s + 1 < nsteps) gload(s + 1);                 // in flight under this step's MFMAs
+    const char* a = smem + (s & 1) * 2 * TILE_BYTES;
+    const char* b = a + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < TM / 32; ++ks) {
+      f16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = frag_tr(a, 32 * ks, 64 * wn + 16 * i, lane);
+        fb[i] = frag_tr(b, 32 * ks, 64 * wk + 16 * i, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (BF16)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                                __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (s + 1 < nsteps) lstore((s + 1) & 1);          // the other buffer: its last readers passed the barrier below
+    __syncthreads();
+  }
+  // accumulator block (i, j): C[n = 4 (lane >> 4) + e][k = lane & 15]
+  float* out = part + (int64_t)blockIdx.z * N * K;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + 64 * wn + 16 * i + 4 * (lane >> 4) + e;
+        const int k = k0 + 64 * wk + 16 * j + (lane & 15);
+        if (n < N && k < K) out[(int64_t)n * K + k] = acc[i][j][e];
+      }
+}
+
+// dW[n][k] = sum over the S slices; K % 4 == 0
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW,
+                                                           int64_t lddw, int N, int K, int S) {
+  const int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const int64_t NK = (int64_t)N * K;
+  if (idx >= NK) return;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < S; ++s) a += *(const f32x4*)(part + (int64_t)s * NK + idx);
+  const int64_t n = idx / K;
+  *(f32x4*)(dW + n * lddw + (idx - n * K)) = a;
+}
+
+// token slices: ~1024 workgroups over the launch, at least 256 tokens per slice, at most 64 slices
+inline int slices(int64_t M, int N, int K) {
+  const int64_t tiles = (int64_t)((N + TN - 1) / TN) * ((K + TK - 1) / TK);
+  int64_t S = 1024 / (tiles > 0 ? tiles : 1);
+  if (S > 64) S = 64;
+  if (S > M / 256) S = M / 256;
+  if (S < 1) S = 1;
+  return (int)S;
+}
+
+// Launch both passes on `s` with TM tokens per step (32 or 64; 64 needs the > 64 KB dynamic-LDS opt-in, done here once per
+// process and device by the caller's flag).  Returns the HIP error of the launches.
+template <bool BF16, int TM>
+inline hipError_t launch(const void* dy16, int64_t lddy, const void* x16, int64_t ldx, int64_t M, int N, int K,
+                         float* dW, int64_t lddw, float* scratch, hipStream_t s) {
+  const int S = slices(M, N, K);
+  const int64_t mper = ((M + S - 1) / S + TM - 1) / TM * TM;
+  const dim3 grid((K + TK - 1) / TK, (N + TN - 1) / TN, S);
+  auto fn = wgrad_tr_kernel<BF16, TM>;
+  if (smem_bytes(TM) > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes(TM));
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(256), smem_bytes(TM), s, (const f16*)dy16, lddy, (const f16*)x16, ldx, scratch, M, N, K,
+                     mper);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((int64_t)N * K / 4 + 255) / 256)), dim3(256), 0, s, scratch, dW,
+                     lddw, N, K, S);
+  return hipGetLastError();
+}
+
+}  // namespace gcd_wgrad
