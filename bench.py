@@ -130,6 +130,16 @@ REFERENCE_AT_SHAPE = dict(value=0.0054, unit="steps/s", cores=8, seconds_per_ste
                               seconds_per_step_max=461.7, steps_per_s=round(1.0 / 268.5, 5), loop_seconds=7036))
 
 
+# The oracle port TIMED AT THE METRIC'S OWN SHAPE on a GPU box's host cores (`bench.py --cpu-baseline-full`, round 4,
+# profiles/r04_bench_cpu_full.json): a recorded constant with provenance, quoted in every default line beside the live
+# FLOP-scaled sample (which overstates the CPU: the small shape runs at 0.64 TFLOP/s, the metric's shape at 0.40).
+PORT_MEASURED_AT_SHAPE = dict(value=0.0045, unit="steps/s", cores=32, seconds_per_step=222.1, kind="port, measured at shape",
+                              provenance="profiles/r04_bench_cpu_full.json: `python bench.py --cpu-baseline-full` on an "
+                                         "MI355X box of this pool, ONE oracle EulerEDM step (UNet on 28 frames, 89.604 "
+                                         "TFLOP) at 14x72x128 latents in 222.1 s = 0.40 TFLOP/s fp32 on 32 threads; "
+                                         "re-measure with --cpu-baseline-full (minutes)")
+
+
 def cpu_baseline_and_parity(net, sampler, fd, T, dev, seed, cond, full=False):
     """cfg0 of BASELINE.json, twice on the same weights and inputs:
       * the oracle (port of the reference's CPU path) on the host cores, timed -> cpu_baseline.
@@ -178,6 +188,7 @@ def cpu_baseline_and_parity(net, sampler, fd, T, dev, seed, cond, full=False):
                        f"in {dt:.1f} s ({tflops:.2f} TFLOP/s fp32, {cores} threads), scaled to "
                        f"14x72x128 by algorithmic FLOPs ({STEP_TFLOP[(72, 128)]} TFLOP/step)",
                 measured_steps_per_s_at_sample=1.0 / dt,
+                measured_at_shape=PORT_MEASURED_AT_SHAPE,
                 reference_at_shape=REFERENCE_AT_SHAPE)
     parity = dict(shape=[T, hw, hw, 4], config="BASELINE.json cfg0 (one EulerEDM step, CFG, 28-frame UNet)",
                   sigma=sig, next_sigma=nxt, rel_l2=rel, tol=PARITY_TOL, ok=bool(rel <= PARITY_TOL),

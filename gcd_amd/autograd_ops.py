@@ -124,14 +124,17 @@ _FUSE_DY_SUMS = os.environ.get("GCD_TRAIN_FUSE_DY_SUMS", "1") != "0"      # A/B 
 # "tr" = gcd_wgrad_tr_f16 (libgcd_amd_train.so, round 4): both operands stay row-major, transposed on the LDS read.
 # Default "tr": same box, interleaved, forward + backward of the full-width step 0.1806 -> 0.1782 s, gradients equal to
 # 2.7e-6 (profiles/r04w_wgrad_ab.txt); shapes the kernel does not take (N or K not multiples of 8) fall back to "gemm".
-WGRAD_IMPL = os.environ.get("GCD_TRAIN_WGRAD", "tr")
+WGRAD_IMPL = "tr"
 
 
 def set_wgrad_impl(name: str) -> None:
     global WGRAD_IMPL
     if name not in ("gemm", "tr"):
-        raise ValueError("wgrad implementation must be 'gemm' or 'tr'")
+        raise ValueError(f"wgrad implementation must be 'gemm' or 'tr', got {name!r}")
     WGRAD_IMPL = name
+
+
+set_wgrad_impl(os.environ.get("GCD_TRAIN_WGRAD", "tr"))     # a typo in the variable raises at import, it does not pick a path
 
 
 def _wgrad(dy16: torch.Tensor, x16: torch.Tensor) -> torch.Tensor:

@@ -1133,6 +1133,10 @@ __global__ __launch_bounds__(256) void attn_temporal_mfma_kernel(const f16* __re
     // ---- V rows -> the wave's LDS tile (row = frame, 128 B + pad) ----
     *(f16x8*)(vs + r15 * TM_ROW + 16 * q) = vc[0];
     *(f16x8*)(vs + r15 * TM_ROW + 64 + 16 * q) = vc[1];
+    // (other lanes read these rows back below: pin the LDS store -> load order inside the wave for any compiler
+    //  version — no instruction is emitted for either)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     // ---- S^T = K Q^T ----
     f32x4 st = {0.f, 0.f, 0.f, 0.f};
     st = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0], qc[0], st, 0, 0, 0);
@@ -1189,6 +1193,9 @@ __global__ __launch_bounds__(256) void attn_temporal_mfma_kernel(const f16* __re
       }
     }
     advance(ph, ps, pb);
+    // the tile's reads are done before the next problem's V rows overwrite it
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     // rotate the slots: j + 1 -> j, the fresh loads -> PF - 1
 #pragma unroll
     for (int j = 0; j + 1 < PF; ++j)

@@ -1,6 +1,7 @@
 // train_wgrad_kernel.h — the device code of gcd_wgrad_tr_f16 (train_wgrad.hip), in a header of its own so that
 // tools/gemm_tr_probe.cpp compiles and fp64-checks EXACTLY the kernels the library launches.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -154,8 +155,17 @@ inline hipError_t launch(const void* dy16, int64_t lddy, const void* x16, int64_
   const dim3 grid((K + TK - 1) / TK, (N + TN - 1) / TN, S);
   auto fn = wgrad_tr_kernel<BF16, TM>;
   if (smem_bytes(TM) > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes(TM));
+    // the > 64 KB dynamic-LDS opt-in: ONE driver call per process, device and instantiation (not one per weight
+    // gradient; also keeps the launch path free of driver calls under stream capture after the first step)
+    static std::atomic<bool> opted[64];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !opted[dev].load(std::memory_order_acquire)) {
+      e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes(TM));
+      if (e != hipSuccess) return e;
+      if (dev >= 0 && dev < 64) opted[dev].store(true, std::memory_order_release);
+    }
   }
   hipLaunchKernelGGL(fn, grid, dim3(256), smem_bytes(TM), s, (const f16*)dy16, lddy, (const f16*)x16, ldx, scratch, M, N, K,
                      mper);

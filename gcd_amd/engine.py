@@ -386,7 +386,12 @@ class UNetEngine:
     def _gemm(self, a16, w16, out, **kw):
         """`ops.gemm` with the walk direction of the zig-zag schedule (gcd_gemm_desc.sched bit 0)."""
         if _ZIGZAG in (1, 2):
-            kw["sched"] = self._next_dir()
+            # only the 256 x 320 tile kernels honour the bit (automatic choice: >= 192 tiles and N >= 160, gemm.hip); a
+            # small launch on the general kernel walks front to back whatever it is told and must not flip the record
+            # the next big launch alternates against
+            M, N = kw["M"], w16.shape[0]
+            if ((M + 255) // 256) * ((N + 319) // 320) >= 192 and N >= 160:
+                kw["sched"] = self._next_dir()
         return ops.gemm(a16, w16, out, **kw)
 
     def _ln(self, x, affine, addvec=None, rows_per_vec=1, sum_out=None):

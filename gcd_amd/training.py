@@ -603,7 +603,10 @@ class GradBucketer:
                     p.grad.copy_(g)
                 off += n
             self._work[i] = None
-        if self._learn_unused:             # static graph: what this pass did not reach stays unreached
+        if self._learn_unused and self._seen:
+            # static graph: what this pass did not reach stays unreached.  Learned only from a pass that DID reach
+            # something: a finish() behind no synchronised backward (a warm-up, a step run wholly under no_sync())
+            # would otherwise mark every parameter unreached and no bucket would launch during the next backward.
             self._unused |= {id(p) for p in self.params if id(p) not in self._seen}
             self._learn_unused = False
         self._seen.clear()

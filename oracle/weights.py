@@ -54,3 +54,30 @@ def synth_inputs(batch_clips: int, T: int, h: int, w: int, context_dim: int, vec
     uc = {"crossattn": torch.zeros_like(c["crossattn"]), "concat": torch.zeros_like(c["concat"]),
           "vector": c["vector"].clone()}
     return noise, c, uc
+
+
+def synth_tensor_heavy(name: str, shape, salt: int = 0, nu: float = 3.0, geglu_gain: float = 1.0) -> torch.Tensor:
+    """Stress variant of synth_tensor: matrix / conv weights drawn from a Student-t with `nu` degrees of freedom (heavy
+    tails: single weights tens of sigma out), scaled to the variance synth_tensor uses; `geglu_gain` multiplies the
+    GEGLU projections (`ff.net.0.proj.*`) so that the fp16 hidden tensor value * gelu(gate) is pushed towards the top
+    of the fp16 range.  Norm scales, biases and blend logits as in synth_tensor."""
+    shape = tuple(shape)
+    if name.endswith("mix_factor") or (name.endswith(".weight") and len(shape) == 1):
+        return synth_tensor(name, shape, salt)
+    g = _gen(name, salt)
+    if name.endswith(".bias"):
+        b = 0.1 * torch.randn(shape, generator=g)
+        return b * geglu_gain if ".ff.net.0.proj." in name else b
+    fan_in = 1
+    for s in shape[1:]:
+        fan_in *= s
+    z = torch.randn(shape, generator=g)
+    chi = sum(torch.randn(shape, generator=g) ** 2 for _ in range(int(nu)))
+    t = z / (chi / nu).sqrt()                       # Student-t(nu): variance nu / (nu - 2)
+    t = t / (nu / (nu - 2.0)) ** 0.5 / (fan_in ** 0.5)
+    return t * geglu_gain if ".ff.net.0.proj." in name else t
+
+
+def synth_state_dict_heavy(shapes: Dict[str, tuple], salt: int = 0, nu: float = 3.0,
+                           geglu_gain: float = 1.0) -> Dict[str, torch.Tensor]:
+    return {k: synth_tensor_heavy(k, v, salt, nu, geglu_gain) for k, v in shapes.items()}

@@ -19,6 +19,10 @@ pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).resolve().parent / "golden"
 TOL_FWD = 2e-3
 TOL_LOOP = 1e-3
+# decoded 576 x 1024 frames of a full loop against the reference loop + reference decoder (measured on procedural
+# weights: 1.07e-3 rel-L2, 70.4 dB): the north_star's "within 1e-3" is asserted on latents, pixels are "PSNR-equivalent"
+TOL_PIXELS = 1.2e-3
+TOL_PSNR_DB = 68.0
 
 
 def _build(cfg, gpu, salt=0):
@@ -68,6 +72,43 @@ def test_unet_forward_vs_reference_golden(gpu, tiny):
     e = rel_l2(out, g["out"])
     assert out.shape == g["out"].shape and out.dtype == torch.float32
     assert e < TOL_FWD, f"UNet forward vs reference golden: rel-L2 {e:.3e}"
+
+
+def test_unet_forward_heavy_tailed_weights_vs_reference_golden(gpu):
+    """fp16 OPERAND-RANGE stress (oracle/make_golden_stress.py): Student-t (nu = 3) weights — single weights tens of
+    sigma out — and GEGLU projections scaled until the reference's hidden tensor value * gelu(gate), which this path
+    keeps in fp16, peaks at ~half of the fp16 range (recorded in the fixture).  The HIP forward must stay finite and
+    inside the forward bar on the output and on every block against the UNMODIFIED reference's fp32 result."""
+    from gcd_amd.video_model import VideoUNet
+    g = torch.load(GOLD / "unet_tiny_heavy.pt")
+    assert 20000.0 < g["geglu_hidden_absmax"] < 65504.0
+    with torch.device("meta"):
+        net = VideoUNet(**O.TINY.as_reference_kwargs())
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net = net.to_empty(device=gpu)
+    net.load_state_dict(weights.synth_state_dict_heavy(shapes, g["salt"], g["nu"], g["geglu_gain"]))
+    net.eval()
+    x, ts, ctx, y, ioi = _unet_inputs(O.TINY, g["T"], g["h"], g["w"], g["input_seed"])
+    net.engine.taps = {}
+    out = net(x.to(gpu), ts.to(gpu), context=ctx.to(gpu), y=y.to(gpu), num_video_frames=g["T"],
+              image_only_indicator=ioi.to(gpu))
+    torch.cuda.synchronize()
+    taps, net.engine.taps = net.engine.taps, None
+    assert torch.isfinite(out).all(), "non-finite output under heavy-tailed weights"
+    errs = {}
+    for k, v in taps.items():
+        assert torch.isfinite(v).all(), k
+        f = v.reshape(-1).cpu()
+        idx = torch.linspace(0, f.numel() - 1, min(4096, f.numel())).long()
+        errs[k] = rel_l2(f[idx], g["tap_samples"][k])
+    worst = max(errs, key=errs.get)
+    e = rel_l2(out, g["out"])
+    print(f"heavy-tailed weights (GEGLU hidden peaks at {g['geglu_hidden_absmax']:.0f}): output rel-L2 {e:.3e}, "
+          f"worst block {worst} {errs[worst]:.3e}")
+    assert set(taps) == set(g["tap_samples"])
+    assert errs[worst] < TOL_FWD and e < TOL_FWD, f"rel-L2 {e:.3e}, block {worst} {errs[worst]:.3e}"
+    del net
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("T,h,w,seed", [(14, 16, 16, 21), (2, 8, 24, 22), (1, 8, 8, 23), (16, 8, 8, 24)])
@@ -496,15 +537,20 @@ def test_sampler_25_steps_72x128_cfg1_vs_reference_golden(gpu):
         got = sample(frames, gd["out_samples"].numel())
         mse = float(((got.double() - gd["out_samples"].double()) ** 2).mean())
         psnr_ref = 10.0 * math.log10(4.0 / max(mse, 1e-30))
+        e_px = rel_l2(got, gd['out_samples'])
         print(f"576x1024 frames, HIP loop + HIP decoder vs REFERENCE loop + REFERENCE decoder: rel-L2 "
-              f"{rel_l2(got, gd['out_samples']):.3e}, PSNR {psnr_ref:.1f} dB on the [-1, 1] range")
-        assert psnr_ref >= 60.0
+              f"{e_px:.3e}, PSNR {psnr_ref:.1f} dB on the [-1, 1] range")
+        # What is claimed: the 1e-3 rel-L2 contract is held on the LATENTS the loop returns (asserted
+        # above); decoded PIXELS are held to "PSNR-equivalent" — the VAE decoder amplifies the 6.7e-4 latent error
+        # ~1.65x, measured 1.07e-3 rel-L2 / 70.4 dB (procedural weights) — with these bars:
+        assert psnr_ref >= TOL_PSNR_DB, f"decoded frames: PSNR {psnr_ref:.1f} dB"
+        assert e_px < TOL_PIXELS, f"decoded frames: rel-L2 {e_px:.3e}"
     frames_ref = decode_first_stage(dec, g["final"].to(gpu), 0.18215, en_and_decode_n_samples_a_time=14).cpu()
     mse = float(((frames.double() - frames_ref.double()) ** 2).mean())
     psnr = 10.0 * math.log10(4.0 / max(mse, 1e-30))
     print(f"576x1024 frames, latent error alone (HIP decoder on both): rel-L2 {rel_l2(frames, frames_ref):.3e}, "
           f"PSNR {psnr:.1f} dB")
-    assert psnr >= 65.0
+    assert psnr >= TOL_PSNR_DB and rel_l2(frames, frames_ref) < TOL_PIXELS
     del dec
     torch.cuda.empty_cache()
 
