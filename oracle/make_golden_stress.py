@@ -9,7 +9,17 @@ and the fixture records, beside the output and the per-block taps, the largest |
 case sits.  tests/test_unet_gpu.py::test_unet_forward_heavy_tailed_weights_vs_reference_golden holds the HIP path to
 "finite and < 2e-3" on it.
 
-  python -m oracle.make_golden_stress        -> tests/golden/unet_tiny_heavy.pt
+Two fixtures, because the two stresses turned out to be different things (measured, round 5, tools/stress_diag.py):
+  unet_tiny_heavy.pt        Student-t weights, GEGLU gain 1: heavy tails alone change nothing (1.64e-3 vs 1.57e-3 for
+                            Gaussian weights at this width) -> held to the forward bar, 2e-3
+  unet_tiny_geglu_range.pt  Student-t weights, GEGLU gain 22 (hidden peaks at 31 710 = 48 % of the fp16 range): finite, no
+                            clamp event — but the forward error is 5.2e-3, and it is 4.9e-3 already at gain 6 (hidden
+                            2 308) and 4.4e-3 with Gaussian weights at gain 22: NOT a range effect.  With the FeedForward
+                            output ~500x the residual it lands on, the stream IS the fp16-operand product chain (48
+                            FeedForwards x ~6e-4 operand rounding each), no longer diluted by an fp32 residual -> held to
+                            "finite, no overflow, < 8e-3", and recorded in DESIGN.md section 5 as the limit of the 1e-3 claim
+
+  python -m oracle.make_golden_stress        -> both fixtures
 """
 from __future__ import annotations
 
@@ -25,10 +35,17 @@ from oracle import ref_shim, svd_unet_ref as O, weights  # noqa: E402
 from oracle.make_golden import sample, unet_inputs       # noqa: E402
 
 OUT = ROOT / "tests" / "golden"
-SALT, NU, GEGLU_GAIN, SEED = 11, 3.0, 22.0, 57
+import os  # noqa: E402
+SALT, SEED = 11, 57
+# The two committed fixtures (NU, GEGLU_GAIN, file).  GOLDEN_STRESS_NU (>= 1e6: Gaussian weights) / GOLDEN_STRESS_GAIN /
+# GOLDEN_STRESS_OUT make ONE diagnostic variant instead (tools/stress_diag.py: which stress an error comes from).
+FIXTURES = [(3.0, 1.0, "unet_tiny_heavy.pt"), (3.0, 22.0, "unet_tiny_geglu_range.pt")]
+if "GOLDEN_STRESS_OUT" in os.environ:
+    FIXTURES = [(float(os.environ.get("GOLDEN_STRESS_NU", "3")), float(os.environ.get("GOLDEN_STRESS_GAIN", "22")),
+                 os.environ["GOLDEN_STRESS_OUT"])]
 
 
-def main():
+def main(NU, GEGLU_GAIN, FNAME):
     torch.manual_seed(0)
     cfg = O.TINY
     VideoUNet, *_ = ref_shim.reference_classes()
@@ -63,10 +80,11 @@ def main():
         "geglu_hidden_absmax": max(hidden_max), "geglu_hidden_absmax_each": hidden_max,
         "weight_absmax_over_sigma": max(float(v.abs().max() / v.std()) for k, v in net.state_dict().items()
                                         if v.ndim > 1),
-    }, OUT / "unet_tiny_heavy.pt")
-    print("unet_tiny_heavy: out std", float(out.std()), "absmax", float(out.abs().max()),
+    }, OUT / FNAME)
+    print(FNAME, ": out std", float(out.std()), "absmax", float(out.abs().max()),
           "| GEGLU hidden absmax", max(hidden_max), "| per GEGLU", [f"{v:.0f}" for v in hidden_max])
 
 
 if __name__ == "__main__":
-    main()
+    for fx in FIXTURES:
+        main(*fx)

@@ -72,9 +72,12 @@ def synth_tensor_heavy(name: str, shape, salt: int = 0, nu: float = 3.0, geglu_g
     for s in shape[1:]:
         fan_in *= s
     z = torch.randn(shape, generator=g)
-    chi = sum(torch.randn(shape, generator=g) ** 2 for _ in range(int(nu)))
-    t = z / (chi / nu).sqrt()                       # Student-t(nu): variance nu / (nu - 2)
-    t = t / (nu / (nu - 2.0)) ** 0.5 / (fan_in ** 0.5)
+    if nu >= 1e6:                                   # (diagnostic: Gaussian weights, only the GEGLU gain)
+        t = z / (fan_in ** 0.5)
+    else:
+        chi = sum(torch.randn(shape, generator=g) ** 2 for _ in range(int(nu)))
+        t = z / (chi / nu).sqrt()                   # Student-t(nu): variance nu / (nu - 2)
+        t = t / (nu / (nu - 2.0)) ** 0.5 / (fan_in ** 0.5)
     return t * geglu_gain if ".ff.net.0.proj." in name else t
 
 
