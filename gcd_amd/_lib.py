@@ -117,12 +117,37 @@ SIGNATURES = {
 
 # libgcd_amd_train.so (include/gcd_amd_train.h): kernels of the fine-tune step only
 TRAIN_LIB_PATH = _PKG / "libgcd_amd_train.so"
-TRAIN_ABI_VERSION = 1
+TRAIN_ABI_VERSION = 2
+
+
+class PackEntry(C.Structure):
+    """gcd_pack_entry (include/gcd_amd_train.h)."""
+    _fields_ = [("src", _vp), ("dst_f", _vp), ("dst_t", _vp),
+                ("f_ns", _i64), ("f_ts", _i64), ("t_cs", _i64), ("t_ts", _i64),
+                ("N", C.c_int32), ("C", C.c_int32), ("taps", C.c_int32), ("mirror", C.c_int32),
+                ("tile0", C.c_int32), ("tiles_c", C.c_int32)]
+
+
+class SmallmProblem(C.Structure):
+    """gcd_smallm_problem (include/gcd_amd_train.h)."""
+    _fields_ = [("x", _vp), ("W", _vp), ("b", _vp), ("y", _vp), ("dx", _vp), ("dW", _vp), ("db", _vp),
+                ("ldx", _i64), ("ldy", _i64), ("lddx", _i64),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("flags", C.c_int32),
+                ("block0", C.c_int32), ("reserved", C.c_int32)]
+
+
 TRAIN_SIGNATURES = {
     "gcd_train_abi_version": (_i, []),
     "gcd_train_last_error": (C.c_char_p, []),
     "gcd_wgrad_tr_scratch_floats": (_i64, [_i64, _i, _i]),
     "gcd_wgrad_tr_f16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _i64, _vp, _i64, _vp]),
+    "gcd_wgrad_tr_f16_ex": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp]),
+    "gcd_train_pack_weights": (_i, [_vp, _i, _i, _i, _vp]),
+    "gcd_blend_fwd_f32": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i64, _vp, _i64, _vp]),
+    "gcd_blend_bwd_f32": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i64, _vp, _i64, _i, _vp, _i64, _vp, _vp]),
+    "gcd_smallm_fwd": (_i, [_vp, _i, _i, _vp]),
+    "gcd_smallm_dgrad": (_i, [_vp, _i, _i, _vp]),
+    "gcd_smallm_wgrad": (_i, [_vp, _i, _i, _vp]),
 }
 
 _lib = None

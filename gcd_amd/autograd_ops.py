@@ -137,13 +137,47 @@ def set_wgrad_impl(name: str) -> None:
 set_wgrad_impl(os.environ.get("GCD_TRAIN_WGRAD", "tr"))     # a typo in the variable raises at import, it does not pick a path
 
 
-def _wgrad(dy16: torch.Tensor, x16: torch.Tensor) -> torch.Tensor:
-    """dW [N, K] fp32 = dY^T X for dy16 [M, N], x16 [M, K] (same 16-bit type, rows = tokens)."""
+# The planned engine (gcd_amd/train_plan.py) sets this to an object with `grad_dest(param) -> fp32 tensor of the parameter's
+# shape | None` and `accumulate`: weight gradients are then written by the kernel STRAIGHT into that tensor, in the
+# parameter's own layout (gcd_wgrad_tr_f16_ex) — no padded temporary, no permuted copy.  None on the autograd path.
+_GRAD_SINK = None
+
+
+def _sink_dest(*params):
+    """The flat-buffer destination of one parameter, or of several that lie back to back in it (q | k | v)."""
+    if _GRAD_SINK is None:
+        return None
+    ds = [_GRAD_SINK.grad_dest(p) for p in params]
+    if any(d is None for d in ds):
+        return None
+    for a, b in zip(ds, ds[1:]):
+        if b.data_ptr() != a.data_ptr() + a.numel() * 4:
+            return None
+    return ds
+
+
+def _wgrad(dy16: torch.Tensor, x16: torch.Tensor, dest: Optional[torch.Tensor] = None, taps: int = 1,
+           n_real: Optional[int] = None, c_real: Optional[int] = None) -> torch.Tensor:
+    """dW [N, K] fp32 = dY^T X for dy16 [M, N], x16 [M, K] (same 16-bit type, rows = tokens).
+    dest (planned engine): write into this tensor instead — element [n][c][tap] of a parameter [n_real][c_real][taps],
+    column k = tap * (K / taps) + c of the contraction (cropped to the real rows / channels); returns dest."""
     M, N = dy16.shape
     K = x16.shape[1]
+    tr_ok = N % 8 == 0 and K % 8 == 0 and dy16.stride(1) == 1 and x16.stride(1) == 1 and \
+        dy16.stride(0) % 8 == 0 and x16.stride(0) % 8 == 0 and dy16.data_ptr() % 16 == 0 and x16.data_ptr() % 16 == 0
+    if dest is not None and tr_ok and dest.is_contiguous() and dest.data_ptr() % 16 == 0:
+        n_real = N if n_real is None else n_real
+        c_real = K // taps if c_real is None else c_real
+        if taps > 1 or c_real % 4 == 0:
+            lib = _lib.load_train()
+            scratch = torch.empty(int(lib.gcd_wgrad_tr_scratch_floats(M, N, K)), dtype=_f32, device=dy16.device)
+            _lib.check_train(lib.gcd_wgrad_tr_f16_ex(
+                dy16.data_ptr(), dy16.stride(0), x16.data_ptr(), x16.stride(0), M, N, K, int(dy16.dtype == _bf16),
+                dest.data_ptr(), c_real, taps, n_real, c_real, int(bool(_GRAD_SINK is not None and _GRAD_SINK.accumulate)),
+                scratch.data_ptr(), scratch.numel(), _stream()), "gcd_wgrad_tr_f16_ex")
+            return dest
     dw = torch.empty(N, K, dtype=_f32, device=dy16.device)
-    if WGRAD_IMPL == "tr" and N % 8 == 0 and K % 8 == 0 and dy16.stride(1) == 1 and x16.stride(1) == 1 and \
-            dy16.stride(0) % 8 == 0 and x16.stride(0) % 8 == 0 and dy16.data_ptr() % 16 == 0 and x16.data_ptr() % 16 == 0:
+    if WGRAD_IMPL == "tr" and tr_ok:
         lib = _lib.load_train()
         scratch = torch.empty(int(lib.gcd_wgrad_tr_scratch_floats(M, N, K)), dtype=_f32, device=dy16.device)
         _lib.check_train(lib.gcd_wgrad_tr_f16(dy16.data_ptr(), dy16.stride(0), x16.data_ptr(), x16.stride(0), M, N, K,
@@ -199,7 +233,7 @@ def _cast16_colsum(dy32: torch.Tensor, dtype: torch.dtype, rows_per_block: Optio
     return y, sums
 
 
-def _grad_contractions(dy32: torch.Tensor, x16: torch.Tensor, w_t16, need_dx: bool, need_dw: bool, dy16=None):
+def _grad_contractions(dy32: torch.Tensor, x16: torch.Tensor, w_t16, need_dx: bool, need_dw: bool, dy16=None, dw_dest=None):
     """The two contractions every Linear-shaped backward needs, on gcd_gemm_f16:
          dX [M, K] = dY [M, N] @ W [N, K]      (w_t16() -> W^T, [K, N], in the backward operand type)
          dW [N, K] = dY^T [N, M] @ X [M, K]    (x16 [M, K]; split-K over the tokens)
@@ -224,7 +258,7 @@ def _grad_contractions(dy32: torch.Tensor, x16: torch.Tensor, w_t16, need_dx: bo
             wtp[:, :N] = wt
             _gemm(dyp, wtp, dx, M=M)
     if need_dw:
-        dw = _wgrad(dy16, _as_dtype(x16, dt))
+        dw = _wgrad(dy16, _as_dtype(x16, dt), dest=dw_dest)
     return dx, dw
 
 
@@ -422,20 +456,24 @@ def _contract_bwd(kind, dy, a16, params, geo, need_da, need_dw, dy16=None, db_pr
         return db_pre if db_pre is not None else _colsum(dy)[0]
     if kind == "lin":
         weight, bias = params
+        dst = _sink_dest(weight) if need_dw[0] else None
         da, dw = _grad_contractions(dy, a16, lambda d: PACK.get(weight, f"lin_t_{d}", _pack_lin_t(d)),
-                                    need_da, need_dw[0], dy16)
+                                    need_da, need_dw[0], dy16,
+                                    dw_dest=None if dst is None else dst[0].reshape(weight.shape[0], -1))
         if dw is not None:
             dw = dw.reshape(weight.shape)
         return da, [dw, bias_grad(bias, need_dw[1])]
     if kind == "qkv":
+        dst = _sink_dest(*params) if all(need_dw) else None
+        n = params[0].shape[0]
         da, dw = _grad_contractions(
             dy, a16,
             lambda d: PACK.get_multi(params, f"qkv_t_{d}",
                                      lambda ws: torch.cat([w.t().to(d) for w in ws], 1).contiguous()),
-            need_da, any(need_dw), dy16)
+            need_da, any(need_dw), dy16,
+            dw_dest=None if dst is None else torch.as_strided(dst[0], (3 * n, params[0].shape[1]), (params[0].shape[1], 1)))
         if dw is None:
             return da, [None, None, None]
-        n = params[0].shape[0]
         return da, [dw[:n], dw[n:2 * n], dw[2 * n:]]
     if kind == "c3":
         weight, bias = params
@@ -476,8 +514,12 @@ def _contract_bwd(kind, dy, a16, params, geo, need_da, need_dw, dy16=None, db_pr
                                         geo["stride"], geo["upsample"], 0, _stream()), "gcd_col2im3x3_f32")
             da = dxp[:, :Cin] if cin_p != Cin else dxp
         if need_dw[0]:
-            dwp = _wgrad(dy16, col)       # dW = dY^T col [cout_p, 9 * cin_p], contraction over the tokens
-            dw = dwp.reshape(cout_p, 3, 3, cin_p).permute(0, 3, 1, 2)[:Cout, :Cin].contiguous()
+            dst = _sink_dest(weight)
+            if dst is not None:           # straight into the parameter's [Cout, Cin, 3, 3] slot, cropped
+                dw = _wgrad(dy16, col, dest=dst[0], taps=9, n_real=Cout, c_real=Cin)
+            else:
+                dwp = _wgrad(dy16, col)       # dW = dY^T col [cout_p, 9 * cin_p], contraction over the tokens
+                dw = dwp.reshape(cout_p, 3, 3, cin_p).permute(0, 3, 1, 2)[:Cout, :Cin].contiguous()
         return da, [dw, bias_grad(bias, need_dw[1])]
     if kind == "t3":
         weight, bias = params
@@ -495,8 +537,12 @@ def _contract_bwd(kind, dy, a16, params, geo, need_da, need_dw, dy16=None, db_pr
             col = torch.empty(M, 3 * Cc, dtype=dt, device=dev)
             check(lib.gcd_im2col_t3_f16(xg.data_ptr(), _ld(xg), col.data_ptr(), M, Cc, geo["T"], geo["HW"],
                                         _stream()), "gcd_im2col_t3_f16")
-            dwp = _wgrad(dy16, col)
-            dw = dwp.reshape(Cout, 3, Cc).permute(0, 2, 1).reshape(Cout, Cc, 3, 1, 1).contiguous()
+            dst = _sink_dest(weight)
+            if dst is not None:
+                dw = _wgrad(dy16, col, dest=dst[0], taps=3, n_real=Cout, c_real=Cc)
+            else:
+                dwp = _wgrad(dy16, col)
+                dw = dwp.reshape(Cout, 3, Cc).permute(0, 2, 1).reshape(Cout, Cc, 3, 1, 1).contiguous()
         return da, [dw, bias_grad(bias, need_dw[1])]
     raise ValueError(kind)
 

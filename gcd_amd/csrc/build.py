@@ -25,7 +25,7 @@ HEADERS = [CSRC / "common.h", CSRC / "gemm_common.h", ROOT / "include" / "gcd_am
 # `sources_digest()`: they cannot change a kernel the sampler step launches.
 LIB_TRAIN = PKG / "libgcd_amd_train.so"
 STAMP_TRAIN = PKG / ".libgcd_amd_train.stamp"
-TRAIN_SOURCES = ["train_wgrad.hip"]
+TRAIN_SOURCES = ["train_wgrad.hip", "train_ops.hip"]
 TRAIN_HEADERS = [ROOT / "include" / "gcd_amd_train.h", CSRC / "train_wgrad_kernel.h"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",

@@ -29,12 +29,13 @@
 #include "train_wgrad_kernel.h"
 
 static thread_local char g_err[512] = "";
-static void set_error(const char* fmt, ...) {
+void gcd_train_set_error(const char* fmt, ...) {     // shared with train_ops.hip
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+#define set_error gcd_train_set_error
 extern "C" const char* gcd_train_last_error(void) { return g_err; }
 extern "C" int gcd_train_abi_version(void) { return GCD_AMD_TRAIN_ABI_VERSION; }
 
@@ -69,10 +70,20 @@ extern "C" int64_t gcd_wgrad_tr_scratch_floats(int64_t M, int N, int K) {
 extern "C" int gcd_wgrad_tr_f16(const void* dy16, int64_t lddy, const void* x16, int64_t ldx, int64_t M, int N, int K,
                                 int bf16, float* dW, int64_t lddw, float* scratch, int64_t scratch_floats,
                                 void* stream) {
+  return gcd_wgrad_tr_f16_ex(dy16, lddy, x16, ldx, M, N, K, bf16, dW, lddw, 1, N, K, 0, scratch, scratch_floats, stream);
+}
+
+extern "C" int gcd_wgrad_tr_f16_ex(const void* dy16, int64_t lddy, const void* x16, int64_t ldx, int64_t M, int N, int K,
+                                   int bf16, float* dW, int64_t lddw, int taps, int N_real, int C_real, int accumulate,
+                                   float* scratch, int64_t scratch_floats, void* stream) {
+  CHECK_ARG(taps >= 1 && taps <= 9 && K % taps == 0 && N_real >= 1 && N_real <= N && C_real >= 1 && C_real <= K / taps,
+            "gcd_wgrad_tr_f16_ex: taps=%d N_real=%d C_real=%d for N=%d K=%d", taps, N_real, C_real, N, K);
+  CHECK_ARG(taps > 1 || (C_real % 4 == 0), "gcd_wgrad_tr_f16_ex: C_real=%d must be a multiple of 4 for taps = 1", C_real);
+  const gcd_wgrad::Layout lay = {taps, N_real, C_real, accumulate};
   CHECK_ARG(dy16 && x16 && dW && scratch, "gcd_wgrad_tr_f16: null pointer");
   CHECK_ARG(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0,
             "gcd_wgrad_tr_f16: M=%lld N=%d K=%d (N and K must be multiples of 8)", (long long)M, N, K);
-  CHECK_ARG(lddy % 8 == 0 && lddy >= N && ldx % 8 == 0 && ldx >= K && lddw % 4 == 0 && lddw >= K,
+  CHECK_ARG(lddy % 8 == 0 && lddy >= N && ldx % 8 == 0 && ldx >= K && (taps > 1 || (lddw % 4 == 0 && lddw >= C_real)),
             "gcd_wgrad_tr_f16: leading dimensions lddy=%lld ldx=%lld lddw=%lld", (long long)lddy, (long long)ldx,
             (long long)lddw);
   CHECK_ARG((((uintptr_t)dy16 | (uintptr_t)x16 | (uintptr_t)dW | (uintptr_t)scratch) & 15) == 0,
@@ -83,11 +94,11 @@ extern "C" int gcd_wgrad_tr_f16(const void* dy16, int64_t lddy, const void* x16,
   hipStream_t s = (hipStream_t)stream;
   hipError_t e;
   if (wgrad_tm(M, N, K) == 64)
-    e = bf16 ? gcd_wgrad::launch<true, 64>(dy16, lddy, x16, ldx, M, N, K, dW, lddw, scratch, s)
-             : gcd_wgrad::launch<false, 64>(dy16, lddy, x16, ldx, M, N, K, dW, lddw, scratch, s);
+    e = bf16 ? gcd_wgrad::launch<true, 64>(dy16, lddy, x16, ldx, M, N, K, dW, lddw, lay, scratch, s)
+             : gcd_wgrad::launch<false, 64>(dy16, lddy, x16, ldx, M, N, K, dW, lddw, lay, scratch, s);
   else
-    e = bf16 ? gcd_wgrad::launch<true, 32>(dy16, lddy, x16, ldx, M, N, K, dW, lddw, scratch, s)
-             : gcd_wgrad::launch<false, 32>(dy16, lddy, x16, ldx, M, N, K, dW, lddw, scratch, s);
+    e = bf16 ? gcd_wgrad::launch<true, 32>(dy16, lddy, x16, ldx, M, N, K, dW, lddw, lay, scratch, s)
+             : gcd_wgrad::launch<false, 32>(dy16, lddy, x16, ldx, M, N, K, dW, lddw, lay, scratch, s);
   if (e != hipSuccess) {
     set_error("gcd_wgrad_tr_f16: launch failed: %s", hipGetErrorString(e));
     return 1;

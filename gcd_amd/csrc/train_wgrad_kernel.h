@@ -123,16 +123,44 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const f16* __restrict__ d
       }
 }
 
-// dW[n][k] = sum over the S slices; K % 4 == 0
+// Destination layout of the folded gradient (gcd_wgrad_tr_f16_ex): the parameter's own shape [N_real][C_real][taps].
+struct Layout {
+  int taps, N_real, C_real, accumulate;
+};
+
+// dW[n][k] = sum over the S slices; K % 4 == 0, taps == 1 (rows of lddw floats; cropped to N_real x C_real, C_real % 4 == 0)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW,
-                                                           int64_t lddw, int N, int K, int S) {
+                                                           int64_t lddw, int N, int K, int S, Layout lay) {
   const int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   const int64_t NK = (int64_t)N * K;
   if (idx >= NK) return;
+  const int64_t n = idx / K;
+  const int k = (int)(idx - n * K);
+  if (n >= lay.N_real || k >= lay.C_real) return;
   f32x4 a = {0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < S; ++s) a += *(const f32x4*)(part + (int64_t)s * NK + idx);
-  const int64_t n = idx / K;
-  *(f32x4*)(dW + n * lddw + (idx - n * K)) = a;
+  f32x4* dst = (f32x4*)(dW + n * lddw + k);
+  if (lay.accumulate) a += *dst;
+  *dst = a;
+}
+
+// taps > 1: K = taps * Kc; thread (n, c) folds the slices of its `taps` columns tap * Kc + c (reads coalesced along c per
+// tap) and writes element [n][c][0 .. taps) of the parameter: `taps` consecutive floats, contiguous across the workgroup.
+__global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(const float* __restrict__ part, float* __restrict__ dW, int N,
+                                                                int K, int S, Layout lay) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)lay.N_real * lay.C_real;
+  if (i >= total) return;
+  const int n = (int)(i / lay.C_real), c = (int)(i - (int64_t)n * lay.C_real);
+  const int Kc = K / lay.taps;
+  const int64_t NK = (int64_t)N * K;
+  float* dst = dW + i * lay.taps;
+  for (int tap = 0; tap < lay.taps; ++tap) {
+    float a = 0.f;
+    const float* src = part + (int64_t)n * K + (int64_t)tap * Kc + c;
+    for (int s = 0; s < S; ++s) a += src[(int64_t)s * NK];
+    dst[tap] = lay.accumulate ? dst[tap] + a : a;
+  }
 }
 
 // token slices: ~1024 workgroups over the launch, at least 256 tokens per slice, at most 64 slices
@@ -149,7 +177,7 @@ inline int slices(int64_t M, int N, int K) {
 // process and device by the caller's flag).  Returns the HIP error of the launches.
 template <bool BF16, int TM>
 inline hipError_t launch(const void* dy16, int64_t lddy, const void* x16, int64_t ldx, int64_t M, int N, int K,
-                         float* dW, int64_t lddw, float* scratch, hipStream_t s) {
+                         float* dW, int64_t lddw, Layout lay, float* scratch, hipStream_t s) {
   const int S = slices(M, N, K);
   const int64_t mper = ((M + S - 1) / S + TM - 1) / TM * TM;
   const dim3 grid((K + TK - 1) / TK, (N + TN - 1) / TN, S);
@@ -171,8 +199,12 @@ inline hipError_t launch(const void* dy16, int64_t lddy, const void* x16, int64_
                      mper);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((int64_t)N * K / 4 + 255) / 256)), dim3(256), 0, s, scratch, dW,
-                     lddw, N, K, S);
+  if (lay.taps > 1)
+    hipLaunchKernelGGL(wgrad_reduce_taps_kernel, dim3((unsigned)(((int64_t)lay.N_real * lay.C_real + 255) / 256)), dim3(256),
+                       0, s, scratch, dW, N, K, S, lay);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((int64_t)N * K / 4 + 255) / 256)), dim3(256), 0, s, scratch, dW,
+                       lddw, N, K, S, lay);
   return hipGetLastError();
 }
 

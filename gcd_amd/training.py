@@ -139,6 +139,20 @@ def _cross_attention_one_key(att, ctx_rows: torch.Tensor) -> torch.Tensor:
 
 
 _GEGLU_PROLOGUE = os.environ.get("GCD_TRAIN_GEGLU_PROLOGUE", "1") != "0"
+# Which engine runs the VideoUNet of the fine-tune step: "planned" = gcd_amd/train_plan.py (round 5: no tape, one autograd
+# node for the whole network, weight gradients written in place, grouped few-row Linears, one pack launch per step);
+# "autograd" = unet_forward_train below (rounds 2-4: one torch.autograd node per operator).  Same kernels, same results.
+TRAIN_ENGINE = "planned"
+
+
+def set_train_engine(name: str) -> None:
+    global TRAIN_ENGINE
+    if name not in ("planned", "autograd"):
+        raise ValueError(f"train engine must be 'planned' or 'autograd', got {name!r}")
+    TRAIN_ENGINE = name
+
+
+set_train_engine(os.environ.get("GCD_TRAIN_ENGINE", "planned"))
 _ADAM_MULTI = os.environ.get("GCD_ADAM_MULTI", "1") != "0"
 
 
@@ -263,10 +277,14 @@ class TrainDenoiser(nn.Module):
         concat = cond.get("concat")
         if concat is not None and concat.numel() > 0:
             x = torch.cat((x, concat.type_as(x)), dim=1)
-        out = unet_forward_train(unet, x, c_noise.reshape(sigma_shape), cond.get("crossattn"),
-                                 cond.get("vector"), additional_model_inputs["num_video_frames"],
-                                 additional_model_inputs["image_only_indicator"],
-                                 use_checkpoint=self.use_checkpoint)
+        if TRAIN_ENGINE == "planned":
+            from .train_plan import unet_forward_planned as run
+        else:
+            run = unet_forward_train
+        out = run(unet, x, c_noise.reshape(sigma_shape), cond.get("crossattn"),
+                  cond.get("vector"), additional_model_inputs["num_video_frames"],
+                  additional_model_inputs["image_only_indicator"],
+                  use_checkpoint=self.use_checkpoint)
         return out * c_out + input * c_skip
 
 
@@ -519,6 +537,11 @@ class GradBucketer:
         if self.active:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+            # the planned engine (train_plan.py) writes .grad itself, so torch's hooks never fire for its parameters: it
+            # calls the listeners below the moment a parameter's gradient is final
+            from . import train_plan
+            self._listener = lambda p: self._on_grad(p) if id(p) in self._bucket_of else None
+            train_plan.GRAD_LISTENERS.append(self._listener)
 
     def _reset_ready(self) -> None:
         for i, b in enumerate(self.buckets):
@@ -617,6 +640,11 @@ class GradBucketer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        if getattr(self, "_listener", None) is not None:
+            from . import train_plan
+            if self._listener in train_plan.GRAD_LISTENERS:
+                train_plan.GRAD_LISTENERS.remove(self._listener)
+            self._listener = None
 
 
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], dist=None, group=None,

@@ -440,8 +440,19 @@ def test_video_resblock_and_transformer_gradients_vs_oracle(gpu):
     assert dead >= 8, "the one-key cross-attention's q / k / norm2 must receive exactly zero gradient"
 
 
+@pytest.fixture
+def train_engine(request):
+    """Run a test on one of the two engines of the fine-tune step (training.TRAIN_ENGINE), restoring the default."""
+    from gcd_amd import training as TR
+    old = TR.TRAIN_ENGINE
+    TR.set_train_engine(request.param)
+    yield request.param
+    TR.set_train_engine(old)
+
+
+@pytest.mark.parametrize("train_engine", ["planned", "autograd"], indirect=True)
 @pytest.mark.parametrize("step", [0, 2500])
-def test_unet_training_step_vs_oracle(gpu, step):
+def test_unet_training_step_vs_oracle(gpu, step, train_engine):
     """BASELINE.json cfg4 at TINY width: denoiser + loss forward, backward through the whole VideoUNet on
     HIP kernels, Adam step — loss, every parameter gradient and the updated parameters vs
     torch.autograd / torch.optim.Adam over the CPU oracle.  step 0: plain mean loss (the focal top-k is
@@ -536,9 +547,10 @@ def test_unet_training_step_vs_oracle(gpu, step):
     assert moved > 0
 
 
+@pytest.mark.parametrize("train_engine", ["planned", "autograd"], indirect=True)
 @pytest.mark.parametrize("dtype,fixture", [("fp16", "train_kubric_32x48.pt"), ("bf16", "train_kubric_32x48.pt"),
                                            ("fp16", "train_kubric_32x48_focal.pt")])
-def test_training_step_full_width_cfg4_vs_reference_golden(gpu, dtype, fixture):
+def test_training_step_full_width_cfg4_vs_reference_golden(gpu, dtype, fixture, train_engine):
     """BASELINE.json cfg4 at its own shape: ONE fine-tune step of the full-width 1.53 B-parameter Kubric VideoUNet on
     2 clips x 14 frames of 32 x 48 latents (N = 28, activation checkpointing as in every GCD config) against the
     UNMODIFIED reference classes' fp32 torch.autograd run on the CPU (oracle/make_golden_cfg4.py): loss, denoiser

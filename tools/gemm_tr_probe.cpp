@@ -76,7 +76,7 @@ static int run(int M, int N, int K, int iters, bool check) {
   CK(hipMalloc(&dW, (size_t)N * K * 4));
   CK(hipMemcpy(dY, hY.data(), hY.size() * 2, hipMemcpyHostToDevice));
   CK(hipMemcpy(dX, hX.data(), hX.size() * 2, hipMemcpyHostToDevice));
-  auto launch = [&]() { CK((gcd_wgrad::launch<BF16, TM>(dY, N, dX, K, M, N, K, dW, K, part, 0))); };
+  auto launch = [&]() { CK((gcd_wgrad::launch<BF16, TM>(dY, N, dX, K, M, N, K, dW, K, gcd_wgrad::Layout{1, N, K, 0}, part, 0))); };
   launch();
   CK(hipDeviceSynchronize());
   int bad = 0;
