@@ -145,6 +145,7 @@ TRAIN_SIGNATURES = {
     "gcd_train_pack_weights": (_i, [_vp, _i, _i, _i, _vp]),
     "gcd_blend_fwd_f32": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i64, _vp, _i64, _vp]),
     "gcd_blend_bwd_f32": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i64, _vp, _i64, _i, _vp, _i64, _vp, _vp]),
+    "gcd_gn_affine_grads": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp]),
     "gcd_smallm_fwd": (_i, [_vp, _i, _i, _vp]),
     "gcd_smallm_dgrad": (_i, [_vp, _i, _i, _vp]),
     "gcd_smallm_wgrad": (_i, [_vp, _i, _i, _vp]),

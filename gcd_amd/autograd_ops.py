@@ -219,7 +219,7 @@ def _gemm(a16, w16, out, **kw):
     return ops.gemm(a16, w16, out, operand_bf16=a16.dtype == _bf16, workspace=_train_ws(a16.device), sched=2, **kw)
 
 
-def _cast16_colsum(dy32: torch.Tensor, dtype: torch.dtype, rows_per_block: Optional[int]):
+def _cast16_colsum(dy32: torch.Tensor, dtype: torch.dtype, rows_per_block: Optional[int], out_sums=None):
     """(dy16, sums [M / rows, N]): the incoming gradient rounded for the GEMMs and its row-block column sums (bias /
     per-frame-vector gradients) in one pass (gcd_cast_colsum_f32); plain cast when no sums are wanted or the width
     is not a multiple of 8."""
@@ -227,7 +227,9 @@ def _cast16_colsum(dy32: torch.Tensor, dtype: torch.dtype, rows_per_block: Optio
     if rows_per_block is None or N % 8:
         return _cast16(dy32, dtype), (None if rows_per_block is None else _colsum(dy32, rows_per_block))
     y = torch.empty(M, N, dtype=dtype, device=dy32.device)
-    sums = torch.zeros(M // rows_per_block, N, dtype=_f32, device=dy32.device)
+    # out_sums (planned engine): the bias's own slot of the flat gradient buffer, zeroed once per step — the kernel's
+    # atomics land there directly (no fill, no copy)
+    sums = out_sums if out_sums is not None else _zeros(M // rows_per_block, N, dy32.device)
     check(_lib.load().gcd_cast_colsum_f32(dy32.data_ptr(), _ld(dy32), y.data_ptr(), _ld(y), M, N, rows_per_block,
                                           sums.data_ptr(), int(dtype == _bf16), _stream()), "gcd_cast_colsum_f32")
     return y, sums
@@ -262,10 +264,20 @@ def _grad_contractions(dy32: torch.Tensor, x16: torch.Tensor, w_t16, need_dx: bo
     return dx, dw
 
 
+def _zeros(m: int, n: int, device) -> torch.Tensor:
+    """A zeroed fp32 [m, n] accumulator: from the planned engine's per-step arena (one memset per step) when it runs,
+    else a fresh torch.zeros (one fill launch each)."""
+    if _GRAD_SINK is not None:
+        z = _GRAD_SINK.zeros(m, n)
+        if z is not None:
+            return z
+    return torch.zeros(m, n, dtype=_f32, device=device)
+
+
 def _colsum(x32: torch.Tensor, rows_per_block: Optional[int] = None) -> torch.Tensor:
     M, N = x32.shape
     rows = M if rows_per_block is None else rows_per_block
-    out = torch.zeros(M // rows, N, dtype=_f32, device=x32.device)
+    out = _zeros(M // rows, N, x32.device)
     check(_lib.load().gcd_rowblock_sum_f32(x32.data_ptr(), _ld(x32), M, N, rows, out.data_ptr(), _stream()),
           "gcd_rowblock_sum_f32")
     return out
@@ -561,7 +573,8 @@ def _gn_fwd(x, gamma, beta, rows_per_inst, eps, silu):
     return y16, stats, g32, b32
 
 
-def _gn_bwd(x, dy, stats, g32, b32, rows_per_inst, silu):
+def _gn_bwd(x, dy, stats, g32, b32, rows_per_inst, silu, dest=None):
+    """dest (planned engine): (dgamma, dbeta) slots of the flat gradient buffer, written by one small kernel."""
     M, Cc = x.shape
     ninst = M // rows_per_inst
     lib = _lib.load()
@@ -574,6 +587,11 @@ def _gn_bwd(x, dy, stats, g32, b32, rows_per_inst, silu):
                                 AB.data_ptr(), scratch.data_ptr(), scratch.numel(), dx.data_ptr(), _ld(dx),
                                 _stream()),
           "gcd_groupnorm_bwd")
+    if dest is not None and dest[0] is not None and dest[1] is not None:
+        _lib.check_train(_lib.load_train().gcd_gn_affine_grads(
+            AB.data_ptr(), ninst, Cc, dest[0].data_ptr(), dest[1].data_ptr(),
+            int(bool(_GRAD_SINK is not None and _GRAD_SINK.accumulate)), _stream()), "gcd_gn_affine_grads")
+        return dx, dest[0], dest[1]
     ab = AB.sum(0).float()
     return dx, ab[:, 1].contiguous(), ab[:, 0].contiguous()
 
@@ -585,11 +603,16 @@ def _ln_fwd(x, gamma, beta, eps):
     return y16, g32
 
 
-def _ln_bwd(x, dy, g32, eps):
+def _ln_bwd(x, dy, g32, eps, dest=None):
+    """dest (planned engine): (dgamma, dbeta) slots of the flat gradient buffer (zeroed once per step): the kernel's
+    atomics accumulate there directly."""
     M, Cc = x.shape
     dx = torch.empty_like(x)
-    dgb = torch.zeros(2, Cc, dtype=_f32, device=x.device)      # one fill for both accumulators
-    dg, db = dgb[0], dgb[1]
+    if dest is not None and dest[0] is not None and dest[1] is not None:
+        dg, db = dest
+    else:
+        dgb = torch.zeros(2, Cc, dtype=_f32, device=x.device)      # one fill for both accumulators
+        dg, db = dgb[0], dgb[1]
     check(_lib.load().gcd_layernorm_bwd(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), M, Cc, g32.data_ptr(),
                                         eps, dx.data_ptr(), _ld(dx), dg.data_ptr(), db.data_ptr(),
                                         _stream()), "gcd_layernorm_bwd")
@@ -677,9 +700,12 @@ class Fused(torch.autograd.Function):
         want_db = has_bias and kind != "qkv" and need_dw[1]
         want_vec = has_vec and nig[3]
         dy16 = db_pre = d_vec = None
+        bias_dest = getattr(ctx, "bias_dest", None)        # planned engine: slots of the flat gradient buffer
+        norm_dest = getattr(ctx, "norm_dest", None)
         if (want_db or want_vec) and _FUSE_DY_SUMS and dy.shape[1] % 8 == 0:
             rows = spec["rows_per_vec"] if want_vec else dy.shape[0]
-            dy16, sums = _cast16_colsum(dy, _dt(GRAD_DTYPE), rows)
+            dy16, sums = _cast16_colsum(dy, _dt(GRAD_DTYPE), rows,
+                                        bias_dest.view(1, -1) if bias_dest is not None and want_db and not want_vec else None)
             if want_vec:
                 d_vec = sums
             if want_db:
@@ -698,10 +724,10 @@ class Fused(torch.autograd.Function):
                                                 _ld(dx), h.shape[0], h.shape[1] // 2, _stream()), "gcd_geglu_bwd_f32")
         elif norm[0] == "ln":
             x, g32 = saved
-            dx, dgamma, dbeta = _ln_bwd(x, da.contiguous(), g32, norm[1])
+            dx, dgamma, dbeta = _ln_bwd(x, da.contiguous(), g32, norm[1], norm_dest)
         else:
             x, g32, stats, b32 = saved
-            dx, dgamma, dbeta = _gn_bwd(x, da.contiguous(), stats, g32, b32, norm[1], norm[3])
+            dx, dgamma, dbeta = _gn_bwd(x, da.contiguous(), stats, g32, b32, norm[1], norm[3], norm_dest)
         d_res = dy if has_res and nig[2] else None
         if want_vec and d_vec is None:
             d_vec = _colsum(dy, spec["rows_per_vec"])

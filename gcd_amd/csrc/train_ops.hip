@@ -153,6 +153,21 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(const float* __restrict_
   }
 }
 
+// GroupNorm affine gradients from gcd_groupnorm_bwd's AB[inst][c][2] (fp64: sum dz, sum dz xhat): dbeta[c] = sum_inst AB[.][c][0],
+// dgamma[c] = sum_inst AB[.][c][1]
+__global__ __launch_bounds__(256) void gn_affine_grads_kernel(const double* __restrict__ AB, int ninst, int C,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int acc) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int i = 0; i < ninst; ++i) {
+    a += AB[((int64_t)i * C + c) * 2];
+    b += AB[((int64_t)i * C + c) * 2 + 1];
+  }
+  dbeta[c] = acc ? dbeta[c] + (float)a : (float)a;
+  dgamma[c] = acc ? dgamma[c] + (float)b : (float)b;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Grouped few-row Linears, fp32 (weights are streamed once; nothing here is matrix-pipe work: <= 32 rows).
 // ---------------------------------------------------------------------------------------------------------------------
@@ -358,6 +373,15 @@ extern "C" int gcd_blend_bwd_f32(const float* dy, int64_t ld_dy, const float* xs
                      xs, ld_s, xt, ld_t, alpha, C / 4, rows_per_frame, d_xs, ld_dxs, accumulate_xs, d_xt, ld_dxt,
                      d_alpha_zeroed);
   T_CHECK_LAUNCH("gcd_blend_bwd_f32");
+  return 0;
+}
+
+extern "C" int gcd_gn_affine_grads(const double* AB, int ninst, int C, float* dgamma, float* dbeta, int accumulate,
+                                   void* stream) {
+  T_CHECK_ARG(AB && dgamma && dbeta && ninst > 0 && C > 0, "gcd_gn_affine_grads: bad arguments");
+  hipLaunchKernelGGL(gn_affine_grads_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, AB, ninst, C,
+                     dgamma, dbeta, accumulate);
+  T_CHECK_LAUNCH("gcd_gn_affine_grads");
   return 0;
 }
 

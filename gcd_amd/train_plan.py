@@ -82,6 +82,9 @@ def _fused_bwd(plan: "TrainPlan", ctx: _Ctx, dy: torch.Tensor, need_x: bool = Tr
     gm = ctx.norm_mod
     want_norm = gm is not None and gm.weight.requires_grad
     ctx.needs_input_grad = (False, need_x, has_res, has_vec and need_vec, want_norm, want_norm, *want)
+    ctx.norm_dest = (plan.grad_dest(gm.weight), plan.grad_dest(gm.bias)) if want_norm else None
+    bias = params[1] if len(params) == 2 else None
+    ctx.bias_dest = plan.grad_dest(bias) if bias is not None and bias.requires_grad else None
     A._GRAD_SINK = plan                    # weight gradients are written in place (autograd_ops._sink_dest)
     try:
         out = A.Fused.backward(ctx, dy)
@@ -109,6 +112,11 @@ def _ln(m):
     return ("ln", m, 1e-5)
 
 
+def zeros_or_new(plan, m, n):
+    z = plan.zeros(m, n)
+    return z if z is not None else torch.zeros(m, n, dtype=_f32, device=plan.device)
+
+
 def _add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """a + b in place on `a` when a is ours to overwrite (a fresh gradient tensor)."""
     return a.add_(b)
@@ -120,8 +128,9 @@ def _add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 class _SmallGroup:
     """A table of independent y = act(x) W^T + b problems of <= 32 rows (gcd_smallm_problem) and the launches over it."""
 
-    def __init__(self, device):
+    def __init__(self, device, name=""):
         self.device = device
+        self.name = name
         self.items: List[dict] = []
         self._tabs: Dict[str, tuple] = {}
 
@@ -140,6 +149,15 @@ class _SmallGroup:
         key = mode
         if key in self._tabs:
             return self._tabs[key]
+        # the device table of this (stage, mode) from the previous step, when every pointer in it is unchanged: the few-row
+        # tensors live in the plan's persistent buffers and arenas, whose bump allocation is deterministic
+        sig = (mode, plan.accumulate if mode == "wgrad" else False) + tuple(
+            (it["x"].data_ptr(), it["y"].data_ptr(), 0 if it.get("dy") is None else it["dy"].data_ptr(),
+             0 if it["dx"] is None else it["dx"].data_ptr()) for it in self.items)
+        hit = plan._table_cache.get((self.name, mode))
+        if hit is not None and hit[0] == sig:
+            self._tabs[key] = hit[1]
+            return hit[1]
         probs, block0 = [], 0
         for it in self.items:
             x, w, y = it["x"], it["w"], it["y"]
@@ -173,12 +191,13 @@ class _SmallGroup:
             probs.append(p)
         if not probs:
             self._tabs[key] = (None, 0, 0)
-            return self._tabs[key]
-        arr = (_lib.SmallmProblem * len(probs))(*probs)
-        dev = torch.empty(C.sizeof(arr), dtype=torch.uint8, device=self.device)
-        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        dev.copy_(host)
-        self._tabs[key] = (dev, len(probs), block0)
+        else:
+            arr = (_lib.SmallmProblem * len(probs))(*probs)
+            dev = torch.empty(C.sizeof(arr), dtype=torch.uint8, device=self.device)
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            dev.copy_(host)
+            self._tabs[key] = (dev, len(probs), block0)
+        plan._table_cache[(self.name, mode)] = (sig, self._tabs[key])
         return self._tabs[key]
 
     def forward(self, plan):
@@ -440,10 +459,37 @@ class TrainPlan:
             self._gview[id(p)] = self.flat[off:off + p.numel()].view(p.shape)
             off += (p.numel() + 3) // 4 * 4
         self._reached = set()
+        # per-step arena of zeroed fp32 accumulators (atomic sums: bias / per-frame-vector gradients, few-row dgrads, blend
+        # partials): ONE memset per step instead of a fill launch per accumulator
+        self._arena = torch.zeros(8 << 20, dtype=_f32, device=dev)
+        self._arena_off = 0
+        # persistent (un-zeroed) storage of the few-row tensors, bump-allocated in the same order every step, so that their
+        # addresses — and with them the grouped launches' device tables — do not change from step to step
+        self._sbuf = torch.empty(16 << 20, dtype=_f32, device=dev)
+        self._sbuf_off = 0
+        self._table_cache: Dict[tuple, tuple] = {}
+        self._pos_in: Dict[tuple, torch.Tensor] = {}
         self._units = self._build_units()
         self._pack_tables = None
         self._pack_dtypes = None
         self._saved = None
+
+    def zeros(self, m: int, n: int) -> Optional[torch.Tensor]:
+        """A zeroed [m, n] view of the step's arena (None when it is exhausted: the caller then allocates)."""
+        need = (m * n + 3) // 4 * 4
+        if self._arena_off + need > self._arena.numel():
+            return None
+        v = self._arena[self._arena_off:self._arena_off + m * n].view(m, n)
+        self._arena_off += need
+        return v
+
+    def snew(self, m: int, n: int) -> torch.Tensor:
+        need = (m * n + 3) // 4 * 4
+        if self._sbuf_off + need > self._sbuf.numel():
+            return torch.empty(m, n, dtype=_f32, device=self.device)
+        v = self._sbuf[self._sbuf_off:self._sbuf_off + m * n].view(m, n)
+        self._sbuf_off += need
+        return v
 
     # ---- gradients ----
     def grad_dest(self, p: torch.Tensor) -> Optional[torch.Tensor]:
@@ -713,7 +759,11 @@ class TrainPlan:
         return x + vec.repeat_interleave(rows, dim=0)
 
     def rowblock_sum(self, x, rows):
-        return A._colsum(x.contiguous(), rows)
+        A._GRAD_SINK = self
+        try:
+            return A._colsum(x.contiguous(), rows)
+        finally:
+            A._GRAD_SINK = None
 
     # ---- forward ----
     def forward(self, x, timesteps, context, y, num_video_frames: int, image_only_indicator):
@@ -732,9 +782,11 @@ class TrainPlan:
         if self._pack_tables is None or self._pack_dtypes != (A._dt(A.FWD_DTYPE), A._dt(A.GRAD_DTYPE)) or not A.PACK._d:
             self.repack()
         self._reached = set()
+        self._arena.zero_()
+        self._arena_off = 0
         self._small_forward(timesteps, context, y)
         n_bl = len(self.res_blocks) + len(self.transformers)
-        self._dalpha = torch.zeros(n_bl, N, dtype=_f32, device=self.device)
+        self._dalpha = zeros_or_new(self, n_bl, N)
         save = not self.use_checkpoint
         h = x.float().permute(0, 2, 3, 1).reshape(N * H * W, -1).contiguous()
         trace = []          # (unit, input, H, W, saved | None)
@@ -801,17 +853,20 @@ class TrainPlan:
         clips = N // T
         adm = unet.adm_in_channels
         E = unet.time_embed[0].weight.shape[0]
+        self._sbuf_off = 0
+        new = self.snew
+        zeros = lambda m, n: zeros_or_new(self, m, n)      # noqa: E731
 
         def temb(t, dim, period):
-            e = torch.empty(t.numel(), dim, device=dev, dtype=_f32)
+            e = new(t.numel(), dim)
             ops.timestep_embedding(t.detach().float().contiguous(), e, float(period))
             return e
-        new = lambda m, n: torch.empty(m, n, dtype=_f32, device=dev)      # noqa: E731
-        zeros = lambda m, n: torch.zeros(m, n, dtype=_f32, device=dev)    # noqa: E731
-        ctx2d = context.reshape(N, -1).float().contiguous()
-        yv = y.float().contiguous()
+        ctx2d = new(N, context.shape[-1])
+        ctx2d.copy_(context.reshape(N, -1))
+        yv = new(N, y.shape[1])
+        yv.copy_(y)
         # stage 1: first Linear of every embedding MLP (inputs known up front)
-        g1 = _SmallGroup(dev)
+        g1 = _SmallGroup(dev, "g1")
         t_in = temb(timesteps, unet.model_channels, getattr(unet, "max_ddpm_temb_period", 10000.0))
         mlps = [(unet.time_embed, t_in), (unet.label_emb[0], yv[:, :adm])]
         if unet.aux_emb_dim > 0:
@@ -819,14 +874,19 @@ class TrainPlan:
         hid = []
         for seq, xin in mlps:
             hid.append(g1.add(xin, seq[0], new(N, seq[0].weight.shape[0])))
-        fidx = torch.arange(T, device=dev, dtype=_f32).repeat(clips)
-        pos_hid, pos_in = [], []
-        for tr in self.transformers:
-            pin = temb(fidx, tr.in_channels, tr.max_time_embed_period)
-            pos_in.append(pin)
+        pos_hid = []
+        for i, tr in enumerate(self.transformers):
+            key = (i, N, T)
+            pin = self._pos_in.get(key)        # the frame-position sinusoids depend on (T, clips) only: made once
+            if pin is None:
+                fidx = torch.arange(T, device=dev, dtype=_f32).repeat(clips)
+                pin = torch.empty(N, tr.in_channels, dtype=_f32, device=dev)
+                ops.timestep_embedding(fidx, pin, float(tr.max_time_embed_period))
+                self._pos_in[key] = pin
             pos_hid.append(g1.add(pin, tr.time_pos_embed[0], new(N, tr.time_pos_embed[0].weight.shape[0])))
         # cross-attention value projections: to_v(ctx) per frame (spatial) / per clip (temporal: first frame's context)
-        ctx_clip = ctx2d[::T].contiguous()
+        ctx_clip = new(clips, ctx2d.shape[1])
+        ctx_clip.copy_(ctx2d[::T])
         cav = []
         for tr in self.transformers:
             row = []
@@ -837,7 +897,7 @@ class TrainPlan:
             cav.append(row)
         g1.forward(self)
         # stage 2: second Linears (SiLU on the hidden rows); emb = sum of the embedding MLPs
-        g2 = _SmallGroup(dev)
+        g2 = _SmallGroup(dev, "g2")
         self._d_hid = [zeros(*h.shape) for h in hid]
         embs = [g2.add(h, seq[2], new(N, E), silu_in=True, dx=self._d_hid[i], dx_silu=True)
                 for i, ((seq, _), h) in enumerate(zip(mlps, hid))]      # (own outputs: problems of a launch run concurrently)
@@ -858,11 +918,12 @@ class TrainPlan:
             self.attn_vecs.append(vecs)
             self._d_cav.append(drow)
         g2.forward(self)
-        emb = embs[0] + embs[1]
+        emb = new(N, E)
+        torch.add(embs[0], embs[1], out=emb)
         for e in embs[2:]:
             emb += e
         # stage 3: the 44 emb_layers on SiLU(emb)
-        g3 = _SmallGroup(dev)
+        g3 = _SmallGroup(dev, "g3")
         self._d_emb = zeros(N, E)
         self.emb_vecs = []
         for rb in self.res_blocks:

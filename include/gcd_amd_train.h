@@ -68,6 +68,11 @@ int gcd_blend_bwd_f32(const float* dy, int64_t ld_dy, const float* xs, int64_t l
                       const float* alpha, int64_t M, int C, int64_t rows_per_frame, float* d_xs, int64_t ld_dxs,
                       int accumulate_xs, float* d_xt, int64_t ld_dxt, float* d_alpha_zeroed, void* stream);
 
+/* GroupNorm affine gradients from the AB[inst][C][2] doubles gcd_groupnorm_bwd (gcd_amd.h) leaves behind:
+ * dbeta[c] (+)= sum over instances of AB[.][c][0], dgamma[c] (+)= ... AB[.][c][1] — one launch instead of a torch reduction,
+ * two slices and two copies per GroupNorm. */
+int gcd_gn_affine_grads(const double* AB, int ninst, int C, float* dgamma, float* dbeta, int accumulate, void* stream);
+
 /* ---- grouped few-row Linears, fp32 ----------------------------------------------------------------------------------------
  * The network's M <= 32-row Linears (emb_layers of the 44 ResBlocks, openaimodel.py:287-293, 343-347; the one-key
  * cross-attention chains to_out(to_v(ctx)), attention.py:272-303; time_pos_embed; the embedding MLPs) as TABLES of
