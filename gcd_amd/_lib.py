@@ -15,7 +15,7 @@ _PKG = Path(__file__).resolve().parent
 # tools; the product is the in-tree library next to this file.
 LIB_PATH = Path(os.environ["GCD_AMD_LIB"]).resolve() if os.environ.get("GCD_AMD_LIB") else _PKG / "libgcd_amd.so"
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # GEMM modes / output kinds (mirror include/gcd_amd.h)
 GEMM_PLAIN, GEMM_CONV3X3, GEMM_TEMPORAL3 = 0, 1, 2
@@ -92,6 +92,7 @@ SIGNATURES = {
     "gcd_layernorm_bwd": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp, _f, _vp, _i64, _vp, _vp, _vp]),
     "gcd_geglu_fwd_f32": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),
     "gcd_geglu_fwd_f16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),
+    "gcd_geglu_fwd_bf16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),
     "gcd_geglu_bwd_f32": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _vp]),
     "gcd_softmax_bwd_rows": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _f, _vp]),
     "gcd_attn_spatial_bwd_ws_bytes": (_i64, [_i, _i, _i]),

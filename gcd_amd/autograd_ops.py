@@ -560,14 +560,15 @@ def _contract_bwd(kind, dy, a16, params, geo, need_da, need_dw, dy16=None, db_pr
 
 
 # ---- norms on raw tensors (the standalone Functions further down and `Fused` share them) ----
-def _gn_fwd(x, gamma, beta, rows_per_inst, eps, silu):
+def _gn_fwd(x, gamma, beta, rows_per_inst, eps, silu, dtype=_f16):
+    """-> the normalised activation as the 16-bit GEMM operand `dtype` (bf16: written directly, one rounding, ABI v7)."""
     M, Cc = x.shape
     ninst = M // rows_per_inst
     nch = ops.gn_nchunks(rows_per_inst, ninst)
     partial = torch.empty(ninst * nch * 64, dtype=torch.float64, device=x.device)
     stats = torch.empty(ninst * 64, dtype=_f32, device=x.device)
     ops.groupnorm_stats(x, None, rows_per_inst, eps, partial, stats, nch)
-    y16 = torch.empty(M, Cc, dtype=_f16, device=x.device)
+    y16 = torch.empty(M, Cc, dtype=dtype, device=x.device)
     g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
     ops.groupnorm_apply(x, None, rows_per_inst, stats, g32, b32, silu, y16)
     return y16, stats, g32, b32
@@ -596,8 +597,8 @@ def _gn_bwd(x, dy, stats, g32, b32, rows_per_inst, silu, dest=None):
     return dx, ab[:, 1].contiguous(), ab[:, 0].contiguous()
 
 
-def _ln_fwd(x, gamma, beta, eps):
-    y16 = torch.empty(x.shape, dtype=_f16, device=x.device)
+def _ln_fwd(x, gamma, beta, eps, dtype=_f16):
+    y16 = torch.empty(x.shape, dtype=dtype, device=x.device)
     g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
     ops.layernorm(x, g32, b32, y16, eps=eps)
     return y16, g32
@@ -641,17 +642,16 @@ class Fused(torch.autograd.Function):
             # rounded once to the operand type, straight into the second Linear
             x = x.contiguous()
             M, H2 = x.shape
-            y16 = torch.empty(M, H2 // 2, dtype=_f16, device=x.device)
-            check(_lib.load().gcd_geglu_fwd_f16(x.data_ptr(), _ld(x), y16.data_ptr(), _ld(y16), M, H2 // 2,
-                                                _stream()), "gcd_geglu_fwd_f16")
-            a16 = _as_dtype(y16, dt)
+            # (bf16 operands: rounded ONCE from fp32 — no fp16 hop, none of fp16's range on the hidden tensor)
+            a16 = torch.empty(M, H2 // 2, dtype=dt, device=x.device)
+            fn = _lib.load().gcd_geglu_fwd_bf16 if dt == _bf16 else _lib.load().gcd_geglu_fwd_f16
+            check(fn(x.data_ptr(), _ld(x), a16.data_ptr(), _ld(a16), M, H2 // 2, _stream()), "gcd_geglu_fwd_16")
         elif norm is not None:
             x = x.contiguous()
             if norm[0] == "ln":
-                y16, g32 = _ln_fwd(x, gamma, beta, norm[1])
+                a16, g32 = _ln_fwd(x, gamma, beta, norm[1], dt)
             else:
-                y16, stats, g32, b32 = _gn_fwd(x, gamma, beta, norm[1], norm[2], norm[3])
-            a16 = _as_dtype(y16, dt)
+                a16, stats, g32, b32 = _gn_fwd(x, gamma, beta, norm[1], norm[2], norm[3], dt)
         elif _F16_PASSTHROUGH and getattr(x, "_gcd_f16", None) is not None and x._gcd_f16[1] == x._version and \
                 x._gcd_f16[0].shape == x.shape:
             # x is the fp32 image of an fp16 tensor an attention core produced: that tensor IS the operand

@@ -472,7 +472,8 @@ __global__ __launch_bounds__(256) void geglu_fwd_kernel(const float* __restrict_
 
 // the same with the result rounded to fp16: the operand of the FeedForward's second Linear, written once
 __global__ __launch_bounds__(256) void geglu_fwd_f16_kernel(const float* __restrict__ h, int64_t ldh,
-                                                            f16* __restrict__ out, int64_t ldo, int64_t M, int H) {
+                                                            f16* __restrict__ out, int64_t ldo, int64_t M, int H,
+                                                            int bf16) {
   const int hv = H >> 3;
   const int64_t total = M * hv;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
@@ -484,8 +485,8 @@ __global__ __launch_bounds__(256) void geglu_fwd_f16_kernel(const float* __restr
     f16x8 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      o[e] = (f16)(a0[e] * gelu_f(g0[e]));
-      o[e + 4] = (f16)(a1[e] * gelu_f(g1[e]));
+      o[e] = gcd_cvt16(a0[e] * gelu_f(g0[e]), bf16 != 0);
+      o[e + 4] = gcd_cvt16(a1[e] * gelu_f(g1[e]), bf16 != 0);
     }
     *(f16x8*)(out + m * ldo + c) = o;
   }
@@ -947,7 +948,18 @@ extern "C" int gcd_geglu_fwd_f16(const float* h, int64_t ldh, void* out16, int64
                     (((uintptr_t)h | (uintptr_t)out16) & 15) == 0,
                 "gcd_geglu_fwd_f16: bad args (H=%d must be a multiple of 8)", H);
   hipLaunchKernelGGL(geglu_fwd_f16_kernel, dim3(grid_for(M * (H / 8))), dim3(256), 0, (hipStream_t)stream, h, ldh,
-                     (f16*)out16, ldo, M, H);
+                     (f16*)out16, ldo, M, H, 0);
+  GCD_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gcd_geglu_fwd_bf16(const float* h, int64_t ldh, void* out16, int64_t ldo, int64_t M, int H,
+                                  void* stream) {
+  GCD_CHECK_ARG(h && out16 && M > 0 && H > 0 && H % 8 == 0 && ldh % 4 == 0 && ldo % 8 == 0 &&
+                    (((uintptr_t)h | (uintptr_t)out16) & 15) == 0,
+                "gcd_geglu_fwd_bf16: bad args (H=%d must be a multiple of 8)", H);
+  hipLaunchKernelGGL(geglu_fwd_f16_kernel, dim3(grid_for(M * (H / 8))), dim3(256), 0, (hipStream_t)stream, h, ldh,
+                     (f16*)out16, ldo, M, H, 1);
   GCD_CHECK_LAUNCH();
   return 0;
 }

@@ -18,8 +18,10 @@ PKG = CSRC.parent
 ROOT = PKG.parent
 LIB = PKG / "libgcd_amd.so"
 STAMP = PKG / ".libgcd_amd.stamp"
-SOURCES = ["runtime.hip", "gemm.hip", "gemm_pp.hip", "gemm_p8.hip", "gemm_p8x.hip", "norm.hip", "attention.hip", "attn_bwd.hip",
+SOURCES = ["runtime.hip", "gemm.hip", "gemm_pp.hip", "gemm_p8.hip", "norm.hip", "attention.hip", "attn_bwd.hip",
            "elementwise.hip", "backward.hip"]
+# records of experiments that lost their A/B: compiled into the ablation / A-B libraries only (tools/libgcd_amd_*.so)
+ABLATION_ONLY_SOURCES = ["gemm_p8x.hip"]
 HEADERS = [CSRC / "common.h", CSRC / "gemm_common.h", ROOT / "include" / "gcd_amd.h"]
 # libgcd_amd_train.so: kernels of the fine-tune step only (include/gcd_amd_train.h).  Its sources are NOT part of
 # `sources_digest()`: they cannot change a kernel the sampler step launches.
@@ -44,7 +46,7 @@ def _digest() -> str:
     for p in [CSRC / s for s in SOURCES] + HEADERS:
         h.update(p.read_bytes())
     h.update(" ".join(FLAGS).encode())
-    return h.hexdigest()
+    return h.hexdigest()      # (ABLATION_ONLY_SOURCES are not in the product library)
 
 
 def sources_digest() -> str:
@@ -129,7 +131,9 @@ def _build_ablation(verbose: bool, name: str = "ablate", defines=("-DGCD_ABLATIO
     objdir.mkdir(parents=True, exist_ok=True)
     out = ROOT / "tools" / f"libgcd_amd_{name}.so"
     procs = []
-    for src in SOURCES:
+    if "-DGCD_ABLATION_BUILD" not in defines:
+        defines = tuple(defines) + ("-DGCD_ABLATION_BUILD",)      # every A/B library carries the ablation-only variants
+    for src in SOURCES + ABLATION_ONLY_SOURCES:
         obj = objdir / (src + ".o")
         cmd = [hipcc, *FLAGS, *defines, "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:

@@ -125,3 +125,19 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+
+// fp32 -> 16-bit operand, as the bit pattern of an f16 slot: fp16 (round to nearest even, the hardware conversion) or, when
+// `bf16`, bfloat16 (round to nearest even; NaN stays NaN).  ABI v7: the normalisation / GEGLU kernels write the fine-tune
+// step's bfloat16 GEMM operands DIRECTLY (one rounding from fp32, no fp16 hop and none of fp16's range).
+#ifdef __HIPCC__
+__device__ __forceinline__ _Float16 gcd_cvt16(float v, bool bf16) {
+  if (bf16) {
+    unsigned u = __float_as_uint(v);
+    unsigned short r;
+    if ((u & 0x7fffffffu) > 0x7f800000u) r = (unsigned short)((u >> 16) | 0x40);
+    else r = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    return __builtin_bit_cast(_Float16, r);
+  }
+  return (_Float16)v;
+}
+#endif

@@ -477,6 +477,13 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
       }
     }
   }
+#ifndef GCD_ABLATION_BUILD
+  // Round 5: the fused LayerNorm in the producer's epilogue and the tile-blocked GEGLU hidden layout were built, are
+  // bit-correct, and measured slower / neutral: they live in the ablation build
+  // (python -m gcd_amd.csrc.build --ablation), not in the product library.
+  GCD_CHECK_ARG(!d->ln_out16 && !d->out_blocked && !d->a_blocked,
+                "gcd_gemm_f16: ln_out16 / out_blocked / a_blocked are compiled into the ablation build only");
+#endif
   if (d->ln_out16) {
     GCD_CHECK_ARG(use_pp && d->N == 320 && d->out_kind == GCD_OUT_F32 && d->ln_gamma && d->ln_beta &&
                       d->ld_ln_out % 4 == 0 && ((uintptr_t)d->ln_out16 & 7) == 0,
@@ -561,6 +568,10 @@ extern "C" int gcd_gemm_colstats_supported(const gcd_gemm_desc* d) {
 }
 
 extern "C" int gcd_gemm_hidden_blocked_supported(int M, int N_geglu, int N_out) {
+#ifndef GCD_ABLATION_BUILD
+  (void)M, (void)N_geglu, (void)N_out;
+  return 0;      // ablation build only (see gcd_gemm_f16)
+#endif
   if (M <= 0 || M % 256 != 0 || N_geglu <= 0 || N_geglu % 320 != 0 || N_out < 160 || N_out % 16 != 0) return 0;
   const int impl = gcd_tune_get(GCD_TUNE_GEMM_IMPL);
   if (impl == 1 || impl == 5 || impl == 6) return 0;          // general kernel forced
@@ -572,6 +583,10 @@ extern "C" int gcd_gemm_hidden_blocked_supported(int M, int N_geglu, int N_out) 
 }
 
 extern "C" int gcd_gemm_ln_fusable(int M, int N, int K, int mode) {
+#ifndef GCD_ABLATION_BUILD
+  (void)M, (void)N, (void)K, (void)mode;
+  return 0;      // ablation build only (see gcd_gemm_f16)
+#endif
   if (N != 320 || K <= 0 || K % 32 != 0 || M <= 0) return 0;
   const int impl = gcd_tune_get(GCD_TUNE_GEMM_IMPL);
   if (impl == 1 || impl == 5 || impl == 6) return 0;

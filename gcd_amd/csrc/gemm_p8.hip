@@ -41,6 +41,7 @@
 
 namespace {
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int P8_BM = 256, P8_BN = 320;
 constexpr int P8_A_BYTES = P8_BM * 128;                  // 32768
 constexpr int P8_W_BYTES = P8_BN * 128;                  // 40960
@@ -73,7 +74,11 @@ static_assert(P8_HALO_W0 + 2 * P8_W_BYTES <= P8_BIAS0, "halo layout must fit bel
   } while (0)
 
 // VAR bits: 2048 persistent (256 workgroups walk the tiles), 4096 per-64-row column statistics (gcd_gemm_desc.colstats),
+// 8192 bfloat16 operands (round 5: the fine-tune step's GEMMs in the type cfg4 names; fp32 outputs only),
 // 16384 split-K (raw fp32 partial sums of K slice L % splitk).
+// Round 5: the product library carries PERSISTENT instantiations only.  A launch of <= 256 tiles runs the same kernel on
+// a grid of its tile count rounded up to a multiple of 8 (every XCD then holds at least its share of workgroups; the
+// surplus ones find no tile and leave) — same tile -> workgroup map as the old one-workgroup-per-tile grid, half the code.
 // Ablation bits (GCD_ABLATION_BUILD only, tools/gemm_bench_ablate; wrong results by design except 4 and 8):
 //   1 no epilogue   2 no K loop (epilogue of zeros)   4 __syncthreads() (vmcnt(0) drain) at the end of a tile instead of
 //   the LDS-only barrier   8 no cross-tile prefetch   16 / 32 / 64 flip the mode's default of: ds_reads before the
@@ -96,6 +101,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
   constexpr bool PERSIST = (VAR & 2048) != 0;
   constexpr bool SPLITK = (VAR & 16384) != 0;
   constexpr bool STATS = (VAR & 4096) != 0;
+  constexpr bool BF16 = (VAR & 8192) != 0;      // bfloat16 operands (v_mfma_f32_16x16x32_bf16): the fine-tune step, cfg4
   constexpr bool READS_FIRST = (MODE == GCD_GEMM_PLAIN) != ((VAR & 16) != 0);
   constexpr bool SETPRIO = (MODE != GCD_GEMM_PLAIN) != ((VAR & 32) != 0);
   constexpr int GM = ((MODE == GCD_GEMM_PLAIN) != ((VAR & 64) != 0)) ? 8 : P8_GROUP_M;
@@ -419,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
       stage_A(1, 1);
       stage_W(1, 1, C1{});
     };
-    if (XPF) {
+    if (XPF && L < L_end) {      // (a surplus workgroup of a rounded-up grid has no tile)
       set_tile(L);
       prologue_a();
     }
@@ -476,8 +482,13 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
           for (int i = 0; i < 5; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-              acc[5 * cp + i][2 * th + j] =
-                  __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i][ks], af[j][ks], acc[5 * cp + i][2 * th + j], 0, 0, 0);
+              if constexpr (BF16)
+                acc[5 * cp + i][2 * th + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, wf[i][ks]), __builtin_bit_cast(bf16x8, af[j][ks]), acc[5 * cp + i][2 * th + j], 0,
+                    0, 0);
+              else
+                acc[5 * cp + i][2 * th + j] =
+                    __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i][ks], af[j][ks], acc[5 * cp + i][2 * th + j], 0, 0, 0);
         if (SETPRIO) __builtin_amdgcn_s_setprio(0);
       };
       using I0 = std::integral_constant<int, 0>;
@@ -764,16 +775,17 @@ int launch_p8(const GemmK& k, hipStream_t s) {
   kk.tiles_n = (k.N + P8_BN - 1) / P8_BN;
   int64_t nblk = (int64_t)kk.tiles_m * kk.tiles_n;
   GCD_CHECK_ARG(nblk > 0 && nblk < (1ll << 31), "gcd_gemm_f16 (p8): bad grid %lld", (long long)nblk);
-  if ((VAR & 2048) && nblk > 256) nblk = 256;   // persistent: one workgroup per CU, 32 per XCD
+  static_assert((VAR & 2048) != 0, "the product library instantiates persistent kernels only");
+  nblk = nblk > 256 ? 256 : (nblk + 7) / 8 * 8;   // one workgroup per CU, 32 per XCD; fewer tiles: a multiple of 8
   hipLaunchKernelGGL(fn, dim3((unsigned)nblk), dim3(512), P8_SMEM_LAUNCH, s, kk);
   GCD_CHECK_LAUNCH();
   return 0;
 }
 
-template <int MODE>
+template <int MODE, int BF = 0>
 int launch_p8_splitk(const GemmK& k, int splitk, float* ws, hipStream_t s) {
   static GcdPerDeviceOnce attr_once;
-  auto fn = gemm_p8_kernel<MODE, 16384>;
+  auto fn = gemm_p8_kernel<MODE, 16384 + BF>;
   GCD_CHECK_HIP(attr_once.opt_in((const void*)fn, P8_SMEM_LAUNCH));
   GemmK kk = k;
   p8_extents<MODE>(kk);
@@ -800,7 +812,8 @@ int launch_p8_splitk(const GemmK& k, int splitk, float* ws, hipStream_t s) {
 bool gcd_gemm_p8_supported(const GemmK& k, int mode) {
   if (k.K % 64 != 0 || k.N % 16 != 0 || k.N < 16) return false;
   if (mode != GCD_GEMM_PLAIN && (k.Cin % 64 != 0 || k.Cin <= 0)) return false;
-  if (k.operand_bf16 || k.ln_out || k.a_blocked || k.out_blocked) return false;
+  if (k.ln_out || k.a_blocked || k.out_blocked) return false;
+  if (k.operand_bf16 && (k.out_kind != GCD_OUT_F32 || k.colstats || k.R2)) return false;   // (what the fine-tune step launches)
   // 32-bit buffer offsets: every offset the kernel forms (rows up to 255 past M / 319 past N included) must stay
   // below the out-of-range marker
   const int64_t a_rows = mode == GCD_GEMM_CONV3X3 ? (int64_t)(k.M / ((int64_t)k.Ho * k.Wo)) * k.Hi * k.Wi : (int64_t)k.M;
@@ -821,13 +834,14 @@ static bool p8_halo_ok(const GemmK& k, int mode) {
   if (mode != GCD_GEMM_CONV3X3 || k.stride != 1 || k.up || k.asym || k.out_kind != GCD_OUT_F32) return false;
   if (k.M % P8_BM != 0 || k.Wo % 64 != 0 || k.Wo > 2040) return false;
   if (!(256 % k.Wo == 0 || k.Wo % 256 == 0)) return false;
-  if (k.Hi != k.Ho || k.Wi != k.Wo || k.K != 9 * k.Cin) return false;
+  if (k.Hi != k.Ho || k.Wi != k.Wo || k.K != 9 * k.Cin || k.operand_bf16) return false;
   return gcd_tune_get(GCD_TUNE_GEMM_IMPL) != 11;
 }
 
 int gcd_gemm_p8_launch(const GemmK& k, int mode, bool persist, hipStream_t s) {
+  (void)persist;      // (round 5: every launch runs a persistent instantiation, see launch_p8)
 #ifdef GCD_ABLATION_BUILD
-  if (gcd_tune_get(GCD_TUNE_GEMM_IMPL) == 12 && persist && mode != GCD_GEMM_PLAIN && k.out_kind == GCD_OUT_F32 && !k.colstats) {
+  if (gcd_tune_get(GCD_TUNE_GEMM_IMPL) == 12 && mode != GCD_GEMM_PLAIN && k.out_kind == GCD_OUT_F32 && !k.colstats && !k.operand_bf16) {
     // A/B: the conv modes without s_setprio and with groups of 8 M-tiles (the PLAIN defaults)
     if (p8_halo_ok(k, mode))
       return k.R2 ? launch_p8<P8_CONV_HALO, 2048 + 96, 4>(k, s) : launch_p8<P8_CONV_HALO, 2048 + 96, 3>(k, s);
@@ -835,9 +849,9 @@ int gcd_gemm_p8_launch(const GemmK& k, int mode, bool persist, hipStream_t s) {
       return k.R2 ? launch_p8<GCD_GEMM_CONV3X3, 2048 + 96, 4>(k, s) : launch_p8<GCD_GEMM_CONV3X3, 2048 + 96, 3>(k, s);
     return k.R2 ? launch_p8<GCD_GEMM_TEMPORAL3, 2048 + 96, 4>(k, s) : launch_p8<GCD_GEMM_TEMPORAL3, 2048 + 96, 3>(k, s);
   }
-  {   // GCD_TUNE_GEMM_IMPL = 64 + ablation bits (PLAIN, persistent grids only)
+  {   // GCD_TUNE_GEMM_IMPL = 64 + ablation bits (PLAIN)
     const int var = gcd_tune_get(GCD_TUNE_GEMM_IMPL) - 64;
-    if (var > 0 && var < 128 && mode == GCD_GEMM_PLAIN && persist && !k.colstats) {
+    if (var > 0 && var < 128 && mode == GCD_GEMM_PLAIN && !k.colstats && !k.operand_bf16) {
       const int epi = k.out_kind == GCD_OUT_GEGLU ? 1 : (k.out_kind == GCD_OUT_F16 && !k.R1 && !k.R2 && !k.frame_alpha) ? 2 : 3;
       if (k.R2) return -1 + 0 * gcd_tune_get(0);   // (no ablation instantiations of the two-residual path)
 #define P8_ABL(V)                                                             \
@@ -863,46 +877,62 @@ int gcd_gemm_p8_launch(const GemmK& k, int mode, bool persist, hipStream_t s) {
     }
   }
 #endif
+  if (k.operand_bf16) {   // gcd_gemm_p8_supported: fp32 rows, at most the first residual, no colstats
+    switch (mode) {
+      case GCD_GEMM_PLAIN:
+        return launch_p8<GCD_GEMM_PLAIN, 2048 + 8192, 3>(k, s);
+      case GCD_GEMM_CONV3X3:
+        return launch_p8<GCD_GEMM_CONV3X3, 2048 + 8192, 3>(k, s);
+      default:
+        return launch_p8<GCD_GEMM_TEMPORAL3, 2048 + 8192, 3>(k, s);
+    }
+  }
   if (p8_halo_ok(k, mode)) {
-    if (k.colstats) return persist ? launch_p8<P8_CONV_HALO, 2048 + 4096>(k, s) : launch_p8<P8_CONV_HALO, 4096>(k, s);
-    if (k.R2) return persist ? launch_p8<P8_CONV_HALO, 2048, 4>(k, s) : launch_p8<P8_CONV_HALO, 0, 4>(k, s);
-    return persist ? launch_p8<P8_CONV_HALO, 2048, 3>(k, s) : launch_p8<P8_CONV_HALO, 0, 3>(k, s);
+    if (k.colstats) return launch_p8<P8_CONV_HALO, 2048 + 4096>(k, s);
+    if (k.R2) return launch_p8<P8_CONV_HALO, 2048, 4>(k, s);
+    return launch_p8<P8_CONV_HALO, 2048, 3>(k, s);
   }
   if (k.colstats) {
     switch (mode) {
       case GCD_GEMM_PLAIN:
-        return persist ? launch_p8<GCD_GEMM_PLAIN, 2048 + 4096>(k, s) : launch_p8<GCD_GEMM_PLAIN, 4096>(k, s);
+        return launch_p8<GCD_GEMM_PLAIN, 2048 + 4096>(k, s);
       case GCD_GEMM_CONV3X3:
-        return persist ? launch_p8<GCD_GEMM_CONV3X3, 2048 + 4096>(k, s) : launch_p8<GCD_GEMM_CONV3X3, 4096>(k, s);
+        return launch_p8<GCD_GEMM_CONV3X3, 2048 + 4096>(k, s);
       default:
-        return persist ? launch_p8<GCD_GEMM_TEMPORAL3, 2048 + 4096>(k, s) : launch_p8<GCD_GEMM_TEMPORAL3, 4096>(k, s);
+        return launch_p8<GCD_GEMM_TEMPORAL3, 2048 + 4096>(k, s);
     }
   }
   switch (mode) {
     case GCD_GEMM_PLAIN:
       // one epilogue fast path per PLAIN instantiation (EPI), chosen from the descriptor
-      if (k.out_kind == GCD_OUT_GEGLU)
-        return persist ? launch_p8<GCD_GEMM_PLAIN, 2048, 1>(k, s) : launch_p8<GCD_GEMM_PLAIN, 0, 1>(k, s);
-      if (k.out_kind == GCD_OUT_F16 && !k.R1 && !k.R2 && !k.frame_alpha)
-        return persist ? launch_p8<GCD_GEMM_PLAIN, 2048, 2>(k, s) : launch_p8<GCD_GEMM_PLAIN, 0, 2>(k, s);
-      if (k.out_kind == GCD_OUT_F16)
-        return persist ? launch_p8<GCD_GEMM_PLAIN, 2048, 5>(k, s) : launch_p8<GCD_GEMM_PLAIN, 0, 5>(k, s);
-      if (k.R2) return persist ? launch_p8<GCD_GEMM_PLAIN, 2048, 4>(k, s) : launch_p8<GCD_GEMM_PLAIN, 0, 4>(k, s);
-      return persist ? launch_p8<GCD_GEMM_PLAIN, 2048, 3>(k, s) : launch_p8<GCD_GEMM_PLAIN, 0, 3>(k, s);
+      if (k.out_kind == GCD_OUT_GEGLU) return launch_p8<GCD_GEMM_PLAIN, 2048, 1>(k, s);
+      if (k.out_kind == GCD_OUT_F16 && !k.R1 && !k.R2 && !k.frame_alpha) return launch_p8<GCD_GEMM_PLAIN, 2048, 2>(k, s);
+      if (k.out_kind == GCD_OUT_F16) return launch_p8<GCD_GEMM_PLAIN, 2048, 5>(k, s);
+      if (k.R2) return launch_p8<GCD_GEMM_PLAIN, 2048, 4>(k, s);
+      return launch_p8<GCD_GEMM_PLAIN, 2048, 3>(k, s);
     case GCD_GEMM_CONV3X3:
       if (k.out_kind != GCD_OUT_F32)   // fp16 / GEGLU outputs of a convolution: the all-paths instantiation
-        return persist ? launch_p8<GCD_GEMM_CONV3X3, 2048>(k, s) : launch_p8<GCD_GEMM_CONV3X3>(k, s);
-      if (k.R2) return persist ? launch_p8<GCD_GEMM_CONV3X3, 2048, 4>(k, s) : launch_p8<GCD_GEMM_CONV3X3, 0, 4>(k, s);
-      return persist ? launch_p8<GCD_GEMM_CONV3X3, 2048, 3>(k, s) : launch_p8<GCD_GEMM_CONV3X3, 0, 3>(k, s);
+        return launch_p8<GCD_GEMM_CONV3X3, 2048>(k, s);
+      if (k.R2) return launch_p8<GCD_GEMM_CONV3X3, 2048, 4>(k, s);
+      return launch_p8<GCD_GEMM_CONV3X3, 2048, 3>(k, s);
     default:
-      if (k.out_kind != GCD_OUT_F32)
-        return persist ? launch_p8<GCD_GEMM_TEMPORAL3, 2048>(k, s) : launch_p8<GCD_GEMM_TEMPORAL3>(k, s);
-      if (k.R2) return persist ? launch_p8<GCD_GEMM_TEMPORAL3, 2048, 4>(k, s) : launch_p8<GCD_GEMM_TEMPORAL3, 0, 4>(k, s);
-      return persist ? launch_p8<GCD_GEMM_TEMPORAL3, 2048, 3>(k, s) : launch_p8<GCD_GEMM_TEMPORAL3, 0, 3>(k, s);
+      if (k.out_kind != GCD_OUT_F32) return launch_p8<GCD_GEMM_TEMPORAL3, 2048>(k, s);
+      if (k.R2) return launch_p8<GCD_GEMM_TEMPORAL3, 2048, 4>(k, s);
+      return launch_p8<GCD_GEMM_TEMPORAL3, 2048, 3>(k, s);
   }
 }
 
 int gcd_gemm_p8_launch_splitk(const GemmK& k, int mode, int splitk, float* ws, hipStream_t s) {
+  if (k.operand_bf16) {
+    switch (mode) {
+      case GCD_GEMM_PLAIN:
+        return launch_p8_splitk<GCD_GEMM_PLAIN, 8192>(k, splitk, ws, s);
+      case GCD_GEMM_CONV3X3:
+        return launch_p8_splitk<GCD_GEMM_CONV3X3, 8192>(k, splitk, ws, s);
+      default:
+        return launch_p8_splitk<GCD_GEMM_TEMPORAL3, 8192>(k, splitk, ws, s);
+    }
+  }
   switch (mode) {
     case GCD_GEMM_PLAIN:
       return launch_p8_splitk<GCD_GEMM_PLAIN>(k, splitk, ws, s);

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmK p) {
     rdW[ks] = PP_A_BYTES + (160 * wn + l31) * 64 + ch;
   }
 
-  if (XPF) {
+  if (XPF && L < L_end) {      // (a surplus workgroup of a rounded-up grid has no tile)
     set_tile(L);
     issue_prologue_a();
   }
@@ -506,7 +506,9 @@ int launch_pp(const GemmK& k, hipStream_t s) {
   kk.tiles_n = (k.N + PP_BN - 1) / PP_BN;
   int64_t nblk = (int64_t)kk.tiles_m * kk.tiles_n;
   GCD_CHECK_ARG(nblk > 0 && nblk < (1ll << 31), "gcd_gemm_f16 (pp): bad grid %lld", (long long)nblk);
-  if ((VAR & 2048) && nblk > 256) nblk = 256;   // persistent: one workgroup per CU, 32 per XCD
+  // Round 5: the product library instantiates PERSISTENT kernels only; <= 256 tiles run on a grid of the tile count
+  // rounded up to a multiple of 8 (same tile -> workgroup map as one workgroup per tile; surplus workgroups find no tile).
+  if (VAR & 2048) nblk = nblk > 256 ? 256 : (nblk + 7) / 8 * 8;
   hipLaunchKernelGGL(fn, dim3((unsigned)nblk), dim3(512), PP_SMEM_LAUNCH, s, kk);
   GCD_CHECK_LAUNCH();
   return 0;
@@ -654,55 +656,58 @@ int gcd_gemm_pp_launch(const GemmK& k, int mode, hipStream_t s) {
     }
   }
 #endif
-  // More tiles than CUs: 256 persistent workgroups walk the tiles (saves the per-workgroup launch /
-  // teardown, 6-7 % on the K = 320 / 640 shapes); otherwise one workgroup per tile.
-  const int64_t tiles = (int64_t)((k.M + PP_BM - 1) / PP_BM) * ((k.N + PP_BN - 1) / PP_BN);
-  const bool persist = tiles > 256 && gcd_tune_get(GCD_TUNE_GEMM_IMPL) != 4;   // knob 4: never persistent
   // the 8-phase K loop (gemm_p8.hip) wherever it applies; knob 3 keeps this file's 32-deep ring kernel.
-  // Knob 10 (only): the GEGLU / q|k|v projections of the large grids on gemm_p8x.hip, the epilogue-under-the-next-
-  // K-loop kernel — correct, and 15-35 % SLOWER than gemm_p8 (profiles/r04g_p8x_ab.txt: its 256 x 160 tiles stage
-  // 48 % more operand bytes per FLOP through the vector-memory -> LDS path), so it is not part of the automatic choice.
   const int impl_knob = gcd_tune_get(GCD_TUNE_GEMM_IMPL);
+#ifdef GCD_ABLATION_BUILD
+  // Knob 10 (ablation build only): the GEGLU / q|k|v projections of the large grids on gemm_p8x.hip, the epilogue-under-
+  // the-next-K-loop kernel — correct, and 15-35 % SLOWER than gemm_p8 (profiles/r04g_p8x_ab.txt).
   if (impl_knob == 10 && gcd_gemm_p8x_supported(k, mode)) return gcd_gemm_p8x_launch(k, s);
-  if (impl_knob != 3 && gcd_gemm_p8_supported(k, mode))
-    return gcd_gemm_p8_launch(k, mode, persist, s);
-  if (k.ln_out) {   // validated by gcd_gemm_f16: PLAIN mode, N == 320
-    if (mode != GCD_GEMM_PLAIN) {
-      gcd_set_error("gcd_gemm_f16: fused LayerNorm is implemented for GCD_GEMM_PLAIN only");
-      return 2;
+#endif
+  if (impl_knob != 3 && gcd_gemm_p8_supported(k, mode)) return gcd_gemm_p8_launch(k, mode, true, s);
+  if (k.ln_out || k.a_blocked) {
+#ifdef GCD_ABLATION_BUILD
+    const int64_t tiles = (int64_t)((k.M + PP_BM - 1) / PP_BM) * ((k.N + PP_BN - 1) / PP_BN);
+    const bool persist = tiles > 256;
+    if (k.ln_out) {   // validated by gcd_gemm_f16: PLAIN mode, N == 320
+      if (mode != GCD_GEMM_PLAIN) {
+        gcd_set_error("gcd_gemm_f16: fused LayerNorm is implemented for GCD_GEMM_PLAIN only");
+        return 2;
+      }
+      return persist ? launch_pp<GCD_GEMM_PLAIN, 2048 + 8192>(k, s) : launch_pp<GCD_GEMM_PLAIN, 8192>(k, s);
     }
-    return persist ? launch_pp<GCD_GEMM_PLAIN, 2048 + 8192>(k, s) : launch_pp<GCD_GEMM_PLAIN, 8192>(k, s);
+    return persist ? launch_pp<GCD_GEMM_PLAIN, 2048 + 32>(k, s) : launch_pp<GCD_GEMM_PLAIN, 32>(k, s);
+#else
+    // (gcd_gemm_f16 refuses these descriptors in the product build; records of experiments that did not pay)
+    gcd_set_error("gcd_gemm_f16: fused LayerNorm / a_blocked exist in the ablation build only");
+    return 2;
+#endif
   }
   if (k.operand_bf16) {   // validated by gcd_gemm_f16: fp32 output, no colstats / LayerNorm / blocked layouts
     switch (mode) {
       case GCD_GEMM_PLAIN:
-        return persist ? launch_pp<GCD_GEMM_PLAIN, 2048 + 65536>(k, s) : launch_pp<GCD_GEMM_PLAIN, 65536>(k, s);
+        return launch_pp<GCD_GEMM_PLAIN, 2048 + 65536>(k, s);
       case GCD_GEMM_CONV3X3:
-        return persist ? launch_pp<GCD_GEMM_CONV3X3, 2048 + 65536>(k, s) : launch_pp<GCD_GEMM_CONV3X3, 65536>(k, s);
+        return launch_pp<GCD_GEMM_CONV3X3, 2048 + 65536>(k, s);
       default:
-        return persist ? launch_pp<GCD_GEMM_TEMPORAL3, 2048 + 65536>(k, s)
-                       : launch_pp<GCD_GEMM_TEMPORAL3, 65536>(k, s);
+        return launch_pp<GCD_GEMM_TEMPORAL3, 2048 + 65536>(k, s);
     }
   }
-  if (k.a_blocked)    // validated by gcd_gemm_f16: PLAIN mode, no colstats / LayerNorm / split-K
-    return persist ? launch_pp<GCD_GEMM_PLAIN, 2048 + 32>(k, s) : launch_pp<GCD_GEMM_PLAIN, 32>(k, s);
   if (k.colstats) {   // validated by gcd_gemm_f16 (colstats_shape_ok)
     switch (mode) {
       case GCD_GEMM_PLAIN:
-        return persist ? launch_pp<GCD_GEMM_PLAIN, 2048 + 4096>(k, s) : launch_pp<GCD_GEMM_PLAIN, 4096>(k, s);
+        return launch_pp<GCD_GEMM_PLAIN, 2048 + 4096>(k, s);
       case GCD_GEMM_CONV3X3:
-        return persist ? launch_pp<GCD_GEMM_CONV3X3, 2048 + 4096>(k, s) : launch_pp<GCD_GEMM_CONV3X3, 4096>(k, s);
+        return launch_pp<GCD_GEMM_CONV3X3, 2048 + 4096>(k, s);
       default:
-        return persist ? launch_pp<GCD_GEMM_TEMPORAL3, 2048 + 4096>(k, s)
-                       : launch_pp<GCD_GEMM_TEMPORAL3, 4096>(k, s);
+        return launch_pp<GCD_GEMM_TEMPORAL3, 2048 + 4096>(k, s);
     }
   }
   switch (mode) {
     case GCD_GEMM_PLAIN:
-      return persist ? launch_pp<GCD_GEMM_PLAIN, 2048>(k, s) : launch_pp<GCD_GEMM_PLAIN>(k, s);
+      return launch_pp<GCD_GEMM_PLAIN, 2048>(k, s);
     case GCD_GEMM_CONV3X3:
-      return persist ? launch_pp<GCD_GEMM_CONV3X3, 2048>(k, s) : launch_pp<GCD_GEMM_CONV3X3>(k, s);
+      return launch_pp<GCD_GEMM_CONV3X3, 2048>(k, s);
     default:
-      return persist ? launch_pp<GCD_GEMM_TEMPORAL3, 2048>(k, s) : launch_pp<GCD_GEMM_TEMPORAL3>(k, s);
+      return launch_pp<GCD_GEMM_TEMPORAL3, 2048>(k, s);
   }
 }

@@ -282,6 +282,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
   float* sh = sc + C;            // [C] shift
   const int cg = C / 32;
   const int order = (silu >> 1) & 3;    // walk order of the (instance, chunk) blocks (gcd_walk; see gcd_amd.h)
+  const bool obf = (silu >> 3) & 1;     // ABI v7: bfloat16 outputs (the fine-tune step's bf16 operands, written directly)
   silu &= 1;
   const int64_t blk = gcd_walk((int64_t)blockIdx.y * gridDim.x + blockIdx.x, (int64_t)gridDim.x * gridDim.y, order);
   const int inst = (int)(blk / gridDim.x);
@@ -318,13 +319,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(
     for (int e = 0; e < 4; ++e) {
       float u = v[e] * a[e] + b[e];
       if (silu) u = silu_f(u);
-      o[e] = (f16)u;
+      o[e] = gcd_cvt16(u, obf);
     }
     gcd_st<NT, f16x4>(y + (base + rr) * ldy + c, o);
     if (raw) {
       f16x4 q;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) q[e] = (f16)v[e];
+      for (int e = 0; e < 4; ++e) q[e] = gcd_cvt16(v[e], obf);
       gcd_st<NT, f16x4>(raw + (base + rr) * ldraw + c, q);
     }
   };
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   const int cv4 = C >> 2;
   const int64_t nrb = (M + 3) >> 2;   // blocks of 4 rows (one per wave), walked in `order`
   for (int64_t pos = blockIdx.x; pos < nrb; pos += gridDim.x) {
-    const int64_t m = gcd_walk(pos, nrb, order) * 4 + (threadIdx.x >> 6);
+    const int64_t m = gcd_walk(pos, nrb, order & 3) * 4 + (threadIdx.x >> 6);
     if (m >= M) continue;
     const float* row = x + m * ldx;
     const float* av = addvec ? addvec + (m / rows_per_vec) * ld_addvec : nullptr;
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
         const f32x4 g = *(const f32x4*)(gamma + cv * 4), b = *(const f32x4*)(beta + cv * 4);
         f16x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (f16)((v[i][e] - mean) * rstd * g[e] + b[e]);
+        for (int e = 0; e < 4; ++e) o[e] = gcd_cvt16((v[i][e] - mean) * rstd * g[e] + b[e], (order & 4) != 0);
         *(f16x4*)(y + m * ldy + cv * 4) = o;
         if (sum_out) *(f32x4*)(sum_out + m * ld_sum + cv * 4) = v[i];
       }
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(
     return v;
   };
   for (int64_t pos = blockIdx.x; pos < nrb; pos += gridDim.x) {
-    const int64_t m = gcd_walk(pos, nrb, order) * RPB + threadIdx.x / LPR;
+    const int64_t m = gcd_walk(pos, nrb, order & 3) * RPB + threadIdx.x / LPR;
     if (m >= M) continue;   // (whole 16- / 32-lane row groups leave together: the DPP sums stay inside a group)
     const float* row = x + m * ldx + l16 * 4;
     f32x4 v[NV];
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(
       const f32x4 g = *(const f32x4*)(gamma + l16 * 4 + RS * i), b = *(const f32x4*)(beta + l16 * 4 + RS * i);
       f16x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (f16)((v[i][e] - mean) * rstd * g[e] + b[e]);
+      for (int e = 0; e < 4; ++e) o[e] = gcd_cvt16((v[i][e] - mean) * rstd * g[e] + b[e], (order & 4) != 0);
       gcd_st<NT, f16x4>(yr + RS * i, o);
       if (sum_out) gcd_st<NT, f32x4>(sum_out + m * ld_sum + l16 * 4 + RS * i, v[i]);
     }
@@ -538,7 +539,7 @@ extern "C" int gcd_layernorm_f16(const float* x, int64_t ldx, int64_t M, int C, 
   if (addvec)
     GCD_CHECK_ARG(rows_per_vec > 0 && ld_addvec % 4 == 0, "gcd_layernorm_f16: addvec geometry");
   if (sum_out) GCD_CHECK_ARG(ld_sum % 4 == 0, "gcd_layernorm_f16: ld_sum alignment");
-  GCD_CHECK_ARG(order >= 0 && order <= 3, "gcd_layernorm_f16: order=%d (0..3)", order);
+  GCD_CHECK_ARG(order >= 0 && order <= 7, "gcd_layernorm_f16: order=%d (0..3, + 4 for bfloat16 output)", order);
   hipStream_t s = (hipStream_t)stream;
   if (C == 320 || C == 640) {   // 16 / 32 lanes per row, 5 vectors per lane
     const int rpb = C == 320 ? 16 : 8;   // rows per 256-thread block

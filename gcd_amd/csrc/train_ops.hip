@@ -231,20 +231,42 @@ __global__ __launch_bounds__(256) void smallm_fwd_kernel(const gcd_smallm_proble
         }
     }
   }
+  // 128 per-lane partial sums (4 columns x 32 rows) -> 128 totals over the 64 lanes by a butterfly REDUCE-SCATTER: at
+  // every step a lane keeps one half of its values and sends the other half to its partner (126 cross-lane moves instead
+  // of the 768 of 128 independent butterflies); lane l ends with the totals of indices 2 l and 2 l + 1, index = 32 j + m.
+  float v[128];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int m = 0; m < SM_MAXM; ++m)
-      if (m < M) {
-        float v = acc[j][m];
+    for (int m = 0; m < SM_MAXM; ++m) v[32 * j + m] = acc[j][m];
+#define SM_RS_STEP(N2, MASK)                                     \
+  {                                                              \
+    const bool up = (lane & (MASK)) != 0;                        \
+    _Pragma("unroll") for (int i = 0; i < (N2); ++i) {           \
+      const float keep = up ? v[i + (N2)] : v[i];                \
+      const float send = up ? v[i] : v[i + (N2)];                \
+      v[i] = keep + __shfl_xor(send, (MASK), 64);                \
+    }                                                            \
+  }
+  SM_RS_STEP(64, 32)
+  SM_RS_STEP(32, 16)
+  SM_RS_STEP(16, 8)
+  SM_RS_STEP(8, 4)
+  SM_RS_STEP(4, 2)
+  SM_RS_STEP(2, 1)
+#undef SM_RS_STEP
+  {
+    const int j = lane >> 4;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0 && nb + j < p.N) {
-          v += p.b ? p.b[nb + j] : 0.f;
-          float* dst = p.y + (int64_t)m * p.ldy + nb + j;
-          *dst = (p.flags & 4) ? *dst + v : v;
-        }
+    for (int e = 0; e < 2; ++e) {
+      const int m = (2 * lane + e) & 31;
+      if (m < M && nb + j < p.N) {
+        const float r = v[e] + (p.b ? p.b[nb + j] : 0.f);
+        float* dst = p.y + (int64_t)m * p.ldy + nb + j;
+        *dst = (p.flags & 4) ? *dst + r : r;
       }
+    }
+  }
 }
 
 // dgrad: dx[m][k] (+)= dact(x[m][k]) * sum_n dy[m][n] W[n][k].  Thread per k (every W row read coalesced along k), a
@@ -294,41 +316,46 @@ __global__ __launch_bounds__(256) void smallm_dgrad_kernel(const gcd_smallm_prob
 __global__ __launch_bounds__(256) void smallm_wgrad_kernel(const gcd_smallm_problem* __restrict__ tab, int n_prob) {
   __shared__ float dys[SM_MAXM * SM_NS];
   const gcd_smallm_problem p = smallm_find(tab, n_prob, (int)blockIdx.x);
-  const int M = p.M, K = p.K, N = p.N;
+  const int M = p.M, K = p.K, N = p.N;       // M: any number of rows, walked 32 at a time
   const int rel = (int)blockIdx.x - p.block0;
   const int kblocks = (K + 255) / 256;
   const int ns = rel / kblocks, kb = rel - ns * kblocks;
   const int n0 = ns * SM_NS, nn = min(N - n0, SM_NS);
-  for (int i = threadIdx.x; i < M * SM_NS; i += 256) {
-    const int m = i >> 6, n = i & 63;
-    dys[i] = n < nn ? p.y[(int64_t)m * p.ldy + n0 + n] : 0.f;
-  }
-  __syncthreads();
-  if (kb == 0 && p.db && (int)threadIdx.x < nn) {
-    float sdb = 0.f;
-    for (int m = 0; m < M; ++m) sdb += dys[m * SM_NS + threadIdx.x];
-    float* dst = p.db + n0 + threadIdx.x;
-    *dst = (p.flags & 8) ? *dst + sdb : sdb;
-  }
   const int k = kb * 256 + threadIdx.x;
-  if (k >= K) return;
-  float xr[SM_MAXM];
-#pragma unroll
-  for (int m = 0; m < SM_MAXM; ++m) {
-    float v = 0.f;
-    if (m < M) {
-      v = p.x[(int64_t)m * p.ldx + k];
-      if (p.flags & 1) v = silu_f(v);
+  for (int m0 = 0; m0 < M; m0 += SM_MAXM) {
+    const int mm = min(SM_MAXM, M - m0);
+    const bool add = (p.flags & 8) || m0 > 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < SM_MAXM * SM_NS; i += 256) {
+      const int m = i >> 6, n = i & 63;
+      dys[i] = (n < nn && m < mm) ? p.y[(int64_t)(m0 + m) * p.ldy + n0 + n] : 0.f;
     }
-    xr[m] = v;
-  }
-  for (int n = 0; n < nn; ++n) {
-    float a = 0.f;
+    __syncthreads();
+    if (kb == 0 && p.db && (int)threadIdx.x < nn) {
+      float sdb = 0.f;
+      for (int m = 0; m < mm; ++m) sdb += dys[m * SM_NS + threadIdx.x];
+      float* dst = p.db + n0 + threadIdx.x;
+      *dst = add ? *dst + sdb : sdb;
+    }
+    if (k < K) {
+      float xr[SM_MAXM];
 #pragma unroll
-    for (int m = 0; m < SM_MAXM; ++m)
-      if (m < M) a += dys[m * SM_NS + n] * xr[m];
-    float* dst = p.dW + (int64_t)(n0 + n) * K + k;
-    *dst = (p.flags & 8) ? *dst + a : a;
+      for (int m = 0; m < SM_MAXM; ++m) {
+        float v = 0.f;
+        if (m < mm) {
+          v = p.x[(int64_t)(m0 + m) * p.ldx + k];
+          if (p.flags & 1) v = silu_f(v);
+        }
+        xr[m] = v;
+      }
+      for (int n = 0; n < nn; ++n) {
+        float a = 0.f;
+#pragma unroll
+        for (int m = 0; m < SM_MAXM; ++m) a += dys[m * SM_NS + n] * xr[m];      // (rows >= mm are zeros on both sides)
+        float* dst = p.dW + (int64_t)(n0 + n) * K + k;
+        *dst = add ? *dst + a : a;
+      }
+    }
   }
 }
 

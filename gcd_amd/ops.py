@@ -274,7 +274,8 @@ def groupnorm_stats_from_colsums(cs1, C1: int, cs2, C2: int, M: int, rows_per_in
 
 def groupnorm_apply(x1, x2, rows_per_inst: int, stats, gamma, beta, silu: bool, y16, raw16=None,
                     reverse: bool = False, order: Optional[int] = None):
-    """order: walk order of the row blocks (0..3, see gcd_groupnorm_apply in gcd_amd.h); `reverse` = order 1."""
+    """order: walk order of the row blocks (0..3, see gcd_groupnorm_apply in gcd_amd.h); `reverse` = order 1.
+    A bfloat16 y16 (and raw16) is written directly, rounded once from fp32 (ABI v7)."""
     _need_gpu(x1, x2, stats, gamma, beta, y16, raw16)
     if order is None:
         order = 1 if reverse else 0
@@ -284,7 +285,8 @@ def groupnorm_apply(x1, x2, rows_per_inst: int, stats, gamma, beta, silu: bool, 
     check(_lib.load().gcd_groupnorm_apply(x1.data_ptr(), _ld(x1), C1, _p(x2),
                                           0 if x2 is None else _ld(x2), C2, M, rows_per_inst,
                                           stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                          int(silu) | (order << 1), y16.data_ptr(), _ld(y16), _p(raw16),
+                                          int(silu) | (order << 1) | (8 if y16.dtype == torch.bfloat16 else 0),
+                                          y16.data_ptr(), _ld(y16), _p(raw16),
                                           0 if raw16 is None else _ld(raw16), _stream()),
           "gcd_groupnorm_apply")
     return y16
@@ -298,7 +300,8 @@ def layernorm(x, gamma, beta, y16, *, eps: float = 1e-5, addvec=None, rows_per_v
                                         beta.data_ptr(), eps, _p(addvec),
                                         0 if addvec is None else _ld(addvec), rows_per_vec,
                                         _p(sum_out), 0 if sum_out is None else _ld(sum_out),
-                                        y16.data_ptr(), _ld(y16), order, _stream()), "gcd_layernorm_f16")
+                                        y16.data_ptr(), _ld(y16), order | (4 if y16.dtype == torch.bfloat16 else 0),
+                                        _stream()), "gcd_layernorm_f16")
     return y16
 
 

@@ -140,7 +140,7 @@ class _SmallGroup:
         w = lin.weight if weight is None else weight
         b = (lin.bias if lin is not None else None) if bias is None else bias
         assert x.dtype == _f32 and y.dtype == _f32 and x.stride(1) == 1 and y.stride(1) == 1
-        assert x.shape[0] <= 32 and x.shape[1] % 4 == 0 and w.is_contiguous()
+        assert x.shape[1] % 4 == 0 and w.is_contiguous()
         self.items.append(dict(x=x, w=w, b=b, y=y, silu=silu_in, acc=accumulate, dx=dx, dx_silu=dx_silu))
         self._tabs.clear()
         return y
@@ -161,34 +161,37 @@ class _SmallGroup:
         probs, block0 = [], 0
         for it in self.items:
             x, w, y = it["x"], it["w"], it["y"]
-            M, K = x.shape
-            N = w.shape[0] if w.dim() == 2 else w.shape[0]
-            p = _lib.SmallmProblem()
-            p.x, p.ldx, p.W = x.data_ptr(), x.stride(0), w.data_ptr()
-            p.M, p.N, p.K = M, N, K
-            p.block0 = block0
-            if mode == "fwd":
-                p.b = 0 if it["b"] is None else it["b"].data_ptr()
-                p.y, p.ldy = y.data_ptr(), y.stride(0)
-                p.flags = int(it["silu"]) | (4 if it["acc"] else 0)
-                block0 += (N + 15) // 16
-            else:
-                dy = it["dy"]
-                p.y, p.ldy = dy.data_ptr(), dy.stride(0)
-                if mode == "dgrad":
-                    if it["dx"] is None:
-                        continue
-                    p.dx, p.lddx = it["dx"].data_ptr(), it["dx"].stride(0)
-                    p.flags = (1 if it["dx_silu"] else 0) | 4
+            Mtot, K = x.shape
+            N = w.shape[0]
+            # forward and dgrad: rows are independent -> one problem per 32 rows; wgrad: one problem, the kernel walks the rows
+            chunks = [(0, Mtot)] if mode == "wgrad" else [(m0, min(32, Mtot - m0)) for m0 in range(0, Mtot, 32)]
+            for m0, M in chunks:
+                p = _lib.SmallmProblem()
+                p.x, p.ldx, p.W = x[m0:].data_ptr(), x.stride(0), w.data_ptr()
+                p.M, p.N, p.K = M, N, K
+                p.block0 = block0
+                if mode == "fwd":
+                    p.b = 0 if it["b"] is None else it["b"].data_ptr()
+                    p.y, p.ldy = y[m0:].data_ptr(), y.stride(0)
+                    p.flags = int(it["silu"]) | (4 if it["acc"] else 0)
+                    block0 += (N + 15) // 16
                 else:
-                    if not w.requires_grad:
-                        continue
-                    p.dW = plan.grad_dest(w).data_ptr()
-                    bb = it["b"]
-                    p.db = 0 if bb is None or not bb.requires_grad else plan.grad_dest(bb).data_ptr()
-                    p.flags = int(it["silu"]) | (8 if plan.accumulate else 0)
-                block0 += ((K + 255) // 256) * ((N + 63) // 64)
-            probs.append(p)
+                    dy = it["dy"]
+                    p.y, p.ldy = dy[m0:].data_ptr(), dy.stride(0)
+                    if mode == "dgrad":
+                        if it["dx"] is None:
+                            continue
+                        p.dx, p.lddx = it["dx"][m0:].data_ptr(), it["dx"].stride(0)
+                        p.flags = (1 if it["dx_silu"] else 0) | 4
+                    else:
+                        if not w.requires_grad:
+                            continue
+                        p.dW = plan.grad_dest(w).data_ptr()
+                        bb = it["b"]
+                        p.db = 0 if bb is None or not bb.requires_grad else plan.grad_dest(bb).data_ptr()
+                        p.flags = int(it["silu"]) | (8 if plan.accumulate else 0)
+                    block0 += ((K + 255) // 256) * ((N + 63) // 64)
+                probs.append(p)
         if not probs:
             self._tabs[key] = (None, 0, 0)
         else:
@@ -436,7 +439,7 @@ class TrainPlan:
     def __init__(self, unet: VideoUNet, use_checkpoint: Optional[bool] = None,
                  on_param_grad: Optional[Callable[[nn.Parameter], None]] = None):
         self.unet = unet
-        self.use_checkpoint = bool(unet.use_checkpoint if use_checkpoint is None else use_checkpoint)
+        self.set_checkpoint(use_checkpoint)
         self.on_param_grad = on_param_grad
         self.accumulate = False
         self.need_dx = False
@@ -459,6 +462,7 @@ class TrainPlan:
             self._gview[id(p)] = self.flat[off:off + p.numel()].view(p.shape)
             off += (p.numel() + 3) // 4 * 4
         self._reached = set()
+        self.graphed = None
         # per-step arena of zeroed fp32 accumulators (atomic sums: bias / per-frame-vector gradients, few-row dgrads, blend
         # partials): ONE memset per step instead of a fill launch per accumulator
         self._arena = torch.zeros(8 << 20, dtype=_f32, device=dev)
@@ -473,6 +477,33 @@ class TrainPlan:
         self._pack_tables = None
         self._pack_dtypes = None
         self._saved = None
+
+    # ---- activation checkpointing: a memory decision, made against 288 GB ----
+    # bytes of unit contexts kept per (L0 token x model channel) when nothing is recomputed: measured on the full-width
+    # network, 2 clips 54.2 GB vs 32.8 GB peak and 8 clips 132 GB vs 47 GB (profiles/r05_train_checkpoint.txt)
+    CTX_BYTES_PER_TOKEN_CHANNEL = 1600
+
+    def set_checkpoint(self, use_checkpoint: Optional[bool]) -> None:
+        """True / False: as told.  None (the caller follows the network's own `use_checkpoint`, True in every GCD config
+        because the reference trains on 80 GB parts): "auto" — recompute only when the contexts would not fit in the free
+        HBM of this device; GCD_TRAIN_CHECKPOINT = on | off | auto overrides."""
+        import os
+        env = os.environ.get("GCD_TRAIN_CHECKPOINT", "")
+        if use_checkpoint is None:
+            pol = env if env in ("on", "off", "auto") else ("auto" if self.unet.use_checkpoint else "off")
+        else:
+            pol = "on" if use_checkpoint else "off"
+        self.checkpoint_policy = pol
+        self.use_checkpoint = pol != "off"
+
+    def _decide_checkpoint(self, tokens: int) -> None:
+        if self.checkpoint_policy != "auto":
+            self.use_checkpoint = self.checkpoint_policy == "on"
+            return
+        need = self.CTX_BYTES_PER_TOKEN_CHANNEL * tokens * self.unet.model_channels * 1.25
+        free, _ = torch.cuda.mem_get_info(self.device)
+        free += torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
+        self.use_checkpoint = need > free - (8 << 30)
 
     def zeros(self, m: int, n: int) -> Optional[torch.Tensor]:
         """A zeroed [m, n] view of the step's arena (None when it is exhausted: the caller then allocates)."""
@@ -774,9 +805,9 @@ class TrainPlan:
         assert N % T == 0 and context.dim() == 3
         if context.shape[1] != 1:
             raise NotImplementedError("gcd_amd implements the single-token (CLIP image) context of SVD / GCD")
-        if N > 32:
-            raise NotImplementedError("TrainPlan: more than 32 frames per step (the few-row Linears hold <= 32 rows)")
         self.N, self.T, self.H, self.W = N, T, H, W
+        if not torch.cuda.is_current_stream_capturing():
+            self._decide_checkpoint(N * H * W)
         self.ioi = image_only_indicator.to(x.device)
         self._alphas: Dict[int, tuple] = {}
         if self._pack_tables is None or self._pack_dtypes != (A._dt(A.FWD_DTYPE), A._dt(A.GRAD_DTYPE)) or not A.PACK._d:
@@ -968,6 +999,97 @@ class TrainPlan:
         self._groups = None
 
 
+class GraphedPlan:
+    """The planned step under two hipGraphs (torch.cuda.graph): after `WARMUP` eager calls with the same signature the
+    forward pass is captured, and the backward pass at the first backward after it; later steps copy the inputs into the
+    static buffers and replay — no Python, no per-launch host work between the kernels.  What stays eager: the loss between
+    the two graphs, the optimizer step, gradient accumulation (a backward that must ADD falls back to the eager pass), any
+    call whose signature differs.  The weight pack (`repack`) is part of the forward graph: it re-reads the parameters the
+    optimizer just changed.  Listeners (GradBucketer) are told about every gradient after the backward graph has been
+    enqueued, i.e. the data-parallel exchange is not overlapped in this mode."""
+    WARMUP = 2
+
+    def __init__(self, plan: TrainPlan):
+        self.plan = plan
+        self.sig = None
+        self.calls = 0
+        self.g_fwd = self.g_bwd = None
+        self.pool = None
+        self.mode = "eager"
+
+    def _reset(self, sig):
+        self.sig, self.calls = sig, 0
+        self.g_fwd = self.g_bwd = None
+        self.static = None
+        self.mode = "eager"
+
+    def forward(self, x, timesteps, context, y, T, ioi):
+        plan = self.plan
+        sig = (tuple(x.shape), tuple(timesteps.shape), tuple(context.shape), tuple(y.shape), tuple(ioi.shape), T,
+               A.FWD_DTYPE, A.GRAD_DTYPE, plan.checkpoint_policy, x.dtype, context.dtype, y.dtype)
+        if sig != self.sig:
+            self._reset(sig)
+        if self.g_fwd is None and self.calls < self.WARMUP:
+            self.calls += 1
+            self.mode = "eager"
+            return plan.forward(x, timesteps, context, y, T, ioi)
+        if self.g_fwd is None:
+            st = dict(x=x.clone(), t=timesteps.clone(), c=context.clone(), y=y.clone(), ioi=ioi.clone())
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                plan.repack()
+                st["out"] = plan.forward(st["x"], st["t"], st["c"], st["y"], T, st["ioi"])
+            self.pool = g.pool()
+            self.g_fwd, self.static = g, st
+            self._T = T
+            self.mode = "captured_fwd"
+            # (the capture enqueued nothing: run it once for this call's result)
+        st = self.static
+        st["x"].copy_(x)
+        st["t"].copy_(timesteps)
+        st["c"].copy_(context)
+        st["y"].copy_(y)
+        st["ioi"].copy_(ioi)
+        self.g_fwd.replay()
+        if self.mode != "captured_fwd":
+            self.mode = "graph"
+        return st["out"]
+
+    def backward(self, d_out):
+        plan = self.plan
+        if self.mode == "eager":
+            return plan.backward(d_out, accumulate=plan.grads_are_live())
+        if plan.grads_are_live():
+            raise NotImplementedError("GraphedPlan: gradient accumulation onto live .grad needs the eager pass "
+                                      "(GCD_TRAIN_GRAPH=0) — the captured backward overwrites")
+        st = self.static
+        if self.g_bwd is None:
+            st["d_out"] = d_out.detach().float().contiguous().clone()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            listeners, GRAD_LISTENERS[:] = list(GRAD_LISTENERS), []       # host callbacks must not run inside a capture
+            cb, plan.on_param_grad = plan.on_param_grad, None
+            try:
+                with torch.cuda.graph(g, pool=self.pool):
+                    plan.backward(st["d_out"], accumulate=False)
+            finally:
+                GRAD_LISTENERS[:] = listeners
+                plan.on_param_grad = cb
+            self.g_bwd = g
+            self.reached = [p for p in plan.unet.parameters() if id(p) in plan._reached]
+        st["d_out"].copy_(d_out)
+        self.g_bwd.replay()
+        for p in self.reached:
+            p.grad = plan._gview[id(p)]
+            if plan.on_param_grad is not None:
+                plan.on_param_grad(p)
+            for fn in GRAD_LISTENERS:
+                fn(p)
+        self.mode = "graph"
+        return None
+
+
 class _PlannedUNet(torch.autograd.Function):
     """The whole VideoUNet as ONE autograd node: forward = TrainPlan.forward, backward = TrainPlan.backward (which fills the
     parameters' .grad itself).  `anchor` is a dummy input that requires grad, so that autograd calls backward."""
@@ -975,16 +1097,30 @@ class _PlannedUNet(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, anchor, x, timesteps, context, y, T, ioi):
         ctx.plan = plan
+        ctx.graphed = USE_GRAPH and plan.graphed is not None
+        if ctx.graphed:
+            return plan.graphed.forward(x, timesteps, context, y, T, ioi)
         return plan.forward(x, timesteps, context, y, T, ioi)
 
     @staticmethod
     def backward(ctx, d_out):
         plan = ctx.plan
-        plan.backward(d_out, accumulate=plan.grads_are_live())
+        if ctx.graphed:
+            plan.graphed.backward(d_out)
+        else:
+            plan.backward(d_out, accumulate=plan.grads_are_live())
         return (None,) * 8
 
 
 _PLANS: Dict[int, TrainPlan] = {}
+# GCD_TRAIN_GRAPH=1: capture the planned forward and backward passes as two hipGraphs after two eager steps (GraphedPlan)
+import os as _os  # noqa: E402
+USE_GRAPH = _os.environ.get("GCD_TRAIN_GRAPH", "0") == "1"
+
+
+def set_use_graph(on: bool) -> None:
+    global USE_GRAPH
+    USE_GRAPH = bool(on)
 
 
 def plan_for(unet: VideoUNet, use_checkpoint: Optional[bool] = None) -> TrainPlan:
@@ -992,9 +1128,10 @@ def plan_for(unet: VideoUNet, use_checkpoint: Optional[bool] = None) -> TrainPla
     if p is None or p.unet is not unet:
         p = TrainPlan(unet, use_checkpoint)
         p._anchor = torch.zeros(1, device=p.device, requires_grad=True)
+        p.graphed = GraphedPlan(p)
         _PLANS[id(unet)] = p
-    elif use_checkpoint is not None:
-        p.use_checkpoint = bool(use_checkpoint)
+    else:
+        p.set_checkpoint(use_checkpoint)
     return p
 
 

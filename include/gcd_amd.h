@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GCD_AMD_ABI_VERSION 6
+#define GCD_AMD_ABI_VERSION 7
 
 /* ---- library ------------------------------------------------------------------------------ */
 int gcd_abi_version(void);
@@ -214,7 +214,8 @@ int gcd_groupnorm_stats_from_colsums(const float* cs1, int C1, const float* cs2,
  * silu: bit 0 = apply SiLU; bits 1-2 = walk order of the row blocks (pure scheduling, cf. gcd_gemm_desc.sched: what
  * the previous launch wrote LAST is what the 256 MB Infinity Cache still holds): 0 front to back, 1 back to front,
  * 2 / 3 the tensor as eight contiguous regions walked concurrently — the order in which a persistent GEMM's eight XCD
- * shares are written — every region back to front (2) / front to back (3).                          */
+ * shares are written — every region back to front (2) / front to back (3).  Bit 3 (ABI v7): y16 / raw16 are BFLOAT16,
+ * rounded once from fp32 (the bf16 GEMM operands of the fine-tune step, cfg4).                      */
 int gcd_groupnorm_apply(const float* x1, int64_t ld1, int C1, const float* x2, int64_t ld2, int C2,
                         int64_t M, int64_t rows_per_inst, const float* stats, const float* gamma,
                         const float* beta, int silu, void* y16, int64_t ldy, void* raw16,
@@ -222,7 +223,7 @@ int gcd_groupnorm_apply(const float* x1, int64_t ld1, int C1, const float* x2, i
 /* LayerNorm over C of (x + addvec[m / rows_per_vec]) -> fp16; optionally writes the fp32 sum back
  * (x_mix = x + time_pos_emb, video_attention.py:283-284).  Replaces nn.LayerNorm at
  * attention.py:519-521 and video_attention.py:50,90-93.  order: walk order of the row blocks, 0..3 as
- * gcd_groupnorm_apply's (ABI v6).                                                                */
+ * gcd_groupnorm_apply's (ABI v6); + 4 (ABI v7): y16 is bfloat16, rounded once from fp32.           */
 int gcd_layernorm_f16(const float* x, int64_t ldx, int64_t M, int C, const float* gamma,
                       const float* beta, float eps, const float* addvec, int64_t ld_addvec,
                       int rows_per_vec, float* sum_out, int64_t ld_sum, void* y16, int64_t ldy,
@@ -342,6 +343,9 @@ int gcd_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy
 int gcd_geglu_fwd_f32(const float* h, int64_t ldh, float* out, int64_t ldo, int64_t M, int H, void* stream);
 /* the forward with the result rounded to fp16 (the operand of FeedForward's second Linear, written once)  */
 int gcd_geglu_fwd_f16(const float* h, int64_t ldh, void* out16, int64_t ldo, int64_t M, int H, void* stream);
+/* ABI v7: the same rounded ONCE to bfloat16 (the fine-tune step with bf16 operands, cfg4: no fp16 hop, none of fp16's
+ * range on the hidden tensor). */
+int gcd_geglu_fwd_bf16(const float* h, int64_t ldh, void* out16, int64_t ldo, int64_t M, int H, void* stream);
 int gcd_geglu_bwd_f32(const float* h, int64_t ldh, const float* dout, int64_t lddo, float* dh, int64_t lddh,
                       int64_t M, int H, void* stream);
 /* Softmax backward over R rows of S scores: dS16 = P16 * (dP - rowsum(P16*dP)) * scale.              */

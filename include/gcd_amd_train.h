@@ -83,7 +83,8 @@ int gcd_gn_affine_grads(const double* AB, int ninst, int C, float* dgamma, float
  *                     4 = atomicAdd into dx (shared by several n slices / problems; zeroed by the caller) — a plain store is
  *                     legal only with N <= 64.  blocks: ceil(K / 256) * ceil(N / 64)
  *   wgrad  dW[n][k] = sum_m y[m][n] act(x[m][k]), db[n] = sum_m y[m][n]    flags: 1 = act is SiLU, 8 = accumulate onto dW / db
- *                     blocks: ceil(K / 256) * ceil(N / 64)
+ *                     blocks: ceil(K / 256) * ceil(N / 64).  M may exceed 32 here (the rows are walked 32 at a time inside
+ *                     the kernel); fwd and dgrad take larger M as several problems of <= 32 rows each
  * block0 = first workgroup of the problem in the launch; entries sorted by block0. */
 typedef struct gcd_smallm_problem {
   const float* x;

@@ -341,14 +341,18 @@ def test_feedforward_tile_blocked_hidden(gpu, gemm_impl):
     b2 = torch.randn(C, generator=g).to(gpu)
     r1 = torch.randn(M, C, generator=g).to(gpu)
     ok = ops.gemm_hidden_blocked_ok(M, 2 * H, C, enabled=True)
-    assert ok == {0: False, 2: True, 3: True, 6: False}[gemm_impl]     # 50 FF-out tiles < 192: automatic says no
+    # Round 5: the blocked hidden layout (measured neutral) is compiled into the ABLATION build only
+    # (tools/libgcd_amd_ablate.so through GCD_AMD_LIB): the product library answers "no" and refuses the descriptors.
+    import os
+    ablation = "ablate" in os.environ.get("GCD_AMD_LIB", "")
+    assert ok == ({0: False, 2: True, 3: True, 6: False}[gemm_impl] if ablation else False)   # 50 FF-out tiles < 192: automatic says no
     hid = torch.empty(M, H, dtype=torch.float16, device=gpu)
     out = torch.empty(M, C, device=gpu)
     ops.gemm(x, w1, hid, M=M, bias=b1, out_kind=ops.OUT_GEGLU)
     ops.gemm(hid, w2, out, M=M, bias=b2, r1=r1)
     if not ok:
         with pytest.raises(Exception, match="out_blocked|a_blocked"):
-            if gemm_impl == 6:
+            if gemm_impl == 6 or not ablation:
                 ops.gemm(x, w1, hid, M=M, bias=b1, out_kind=ops.OUT_GEGLU, out_blocked=True)
             else:                                 # automatic: the GEGLU launch is large enough, FF-out is not
                 ops.gemm(hid, w2, out, M=M, bias=b2, r1=r1, a_blocked=True)

@@ -124,6 +124,8 @@ def test_grouped_few_row_linears(gpu):
     from gcd_amd import _lib
     g = torch.Generator().manual_seed(11)
     shapes = [(28, 1280, 320, True), (28, 100, 72, False), (2, 64, 1280, False), (7, 36, 260, True)]   # (M, N, K, silu)
+    # (more than 32 rows — 8 clips of 14 frames — go through train_plan._SmallGroup, which cuts forward / dgrad into 32-row
+    #  problems; the wgrad kernel walks the rows itself: test_planned_engine_many_frames)
     lib = _lib.load_train()
     wide = torch.randn(28, 400, generator=g)
     items = []
@@ -235,3 +237,84 @@ def test_planned_engine_matches_autograd_engine(gpu, ckpt):
     tot = (num / den) ** 0.5
     print(f"planned vs autograd: {len(ga)} gradients, global {tot:.2e}, worst {worst[0]} {worst[1]:.2e}")
     assert tot < 5e-3 and worst[1] < 2e-2
+
+
+def test_planned_engine_under_hipgraphs_matches_eager(gpu):
+    """GraphedPlan: two eager steps, then the forward and backward passes are captured as hipGraphs and replayed.  Five
+    steps with fresh inputs and a parameter update in between (written through raw storage like gcd_adam_step_multi, so
+    that only the in-graph weight pack can see it; a fixed perturbation rather than Adam, whose first steps are
+    lr * sign(g) and turn a last-bit gradient difference into a different trajectory): the replayed steps' outputs and
+    gradients equal an eager run's from the same parameters."""
+    from gcd_amd import autograd_ops as A, train_plan as TP, training as TR
+    cfg = O.TINY
+    T, H, W = 4, 16, 16
+    g = torch.Generator().manual_seed(33)
+    steps = []
+    for _ in range(5):
+        steps.append(dict(x=torch.randn(2 * T, 8, H, W, generator=g).to(gpu), ts=torch.rand(2 * T, generator=g).to(gpu) * 2 - 1,
+                          ctx=torch.randn(2 * T, 1, cfg.context_dim, generator=g).to(gpu),
+                          y=torch.randn(2 * T, cfg.adm_in_channels + cfg.aux_emb_dim, generator=g).clamp(-1, 1).to(gpu),
+                          tgt=torch.randn(2 * T, 4, H, W, generator=g).to(gpu)))
+    ioi = torch.zeros(2, T, device=gpu)
+    runs = {}
+    for graph in (False, True):
+        TP.set_use_graph(graph)
+        try:
+            net = _tiny(gpu, salt=7)
+            A.PACK.clear()
+            outs = []
+            gp = torch.Generator(device=gpu).manual_seed(5)
+            for st in steps:
+                for p in net.parameters():
+                    p.grad = None
+                out = TP.unet_forward_planned(net, st["x"], st["ts"], st["ctx"], st["y"], T, ioi, use_checkpoint=True)
+                ((out - st["tgt"]) ** 2).mean().mul(64.0).backward()
+                outs.append((out.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
+                with torch.no_grad():
+                    for p in net.parameters():
+                        p.data.view(-1).add_(torch.randn(p.numel(), generator=gp, device=gpu) * 0.02 * float(p.data.std() if p.numel() > 1 else 1.0))
+                A.PACK.clear()         # what AdamHIP.step does after writing the parameters through raw pointers
+            torch.cuda.synchronize()
+            if graph:
+                assert TP.plan_for(net).graphed.mode == "graph", "the steps after the warm-up must have been replays"
+            runs[graph] = outs
+        finally:
+            TP.set_use_graph(False)
+    for i, ((oe, ge), (og, gg)) in enumerate(zip(runs[False], runs[True])):
+        assert rel_l2(og, oe) < 1e-4, f"step {i}: output {rel_l2(og, oe):.2e}"
+        assert ge.keys() == gg.keys()
+        worst = max(rel_l2(gg[n], ge[n]) for n in ge if ge[n].numel() >= 64)
+        print(f"step {i}: graph vs eager output {rel_l2(og, oe):.1e}, worst gradient {worst:.1e}")
+        assert worst < 2e-3      # (atomic summation order differs run to run; a stale pack or input would be O(1))
+
+
+def test_planned_engine_many_frames(gpu):
+    """5 clips x 8 frames = 40 frames (> the 32 rows one few-row problem holds): planned vs autograd engine."""
+    from gcd_amd import autograd_ops as A, training as TR
+    from gcd_amd.train_plan import unet_forward_planned
+    net = _tiny(gpu, salt=9)
+    cfg = O.TINY
+    g = torch.Generator().manual_seed(41)
+    T, clips, H, W = 8, 5, 8, 8
+    n = T * clips
+    x = torch.randn(n, 8, H, W, generator=g).to(gpu)
+    ts = torch.linspace(-1.0, 1.5, n).to(gpu)
+    ctx = torch.randn(n, 1, cfg.context_dim, generator=g).to(gpu)
+    y = torch.randn(n, cfg.adm_in_channels + cfg.aux_emb_dim, generator=g).clamp(-1, 1).to(gpu)
+    ioi = torch.zeros(clips, T, device=gpu)
+    tgt = torch.randn(n, 4, H, W, generator=g).to(gpu)
+    res = {}
+    for name, fn in (("autograd", TR.unet_forward_train), ("planned", unet_forward_planned)):
+        A.PACK.clear()
+        for p in net.parameters():
+            p.grad = None
+        out = fn(net, x, ts, ctx, y, T, ioi, use_checkpoint=False)
+        ((out - tgt) ** 2).mean().mul(64.0).backward()
+        torch.cuda.synchronize()
+        res[name] = (out.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    (oa, ga), (op, gp) = res["autograd"], res["planned"]
+    assert rel_l2(op, oa) < 3e-3
+    num = sum(float((gp[k].double() - v.double()).pow(2).sum()) for k, v in ga.items())
+    den = sum(float(v.double().pow(2).sum()) for v in ga.values())
+    print(f"40 frames: output {rel_l2(op, oa):.2e}, gradients {(num / den) ** 0.5:.2e}")
+    assert (num / den) ** 0.5 < 5e-3

@@ -21,6 +21,12 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from bench import build_model  # noqa: E402
 
 
+def _graph_mode(net):
+    from gcd_amd import train_plan as TP
+    p = TP._PLANS.get(id(net))
+    return None if p is None or not TP.USE_GRAPH else p.graphed.mode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=3)
@@ -28,6 +34,9 @@ def main():
     ap.add_argument("--clips", type=int, default=2)
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"],
                     help="operand type of the GEMM-family contractions, forward and backward (cfg4 names bf16)")
+    ap.add_argument("--checkpoint", default="net", choices=["net", "on", "off"],
+                    help="activation checkpointing: the network's own flag (True in every GCD config), forced on, or off "
+                         "(keep every unit's contexts: no re-forward in the backward pass; 288 GB of HBM hold them)")
     ap.add_argument("--ddp", action="store_true", help="run under torchrun: GradBucketer over the nccl (= RCCL) backend")
     a = ap.parse_args()
     import os
@@ -46,7 +55,8 @@ def main():
     h, w = (int(v) for v in a.latent.split("x"))
     BT = a.clips * T
     net = build_model(dev, seed=0).train()
-    den = TR.TrainDenoiser({"target": "gcd_amd.denoiser_scaling.VScalingWithEDMcNoise"})
+    den = TR.TrainDenoiser({"target": "gcd_amd.denoiser_scaling.VScalingWithEDMcNoise"},
+                           use_checkpoint={"net": None, "on": True, "off": False}[a.checkpoint])
     loss_fn = TR.StandardDiffusionLoss(
         sigma_sampler_config={"target": "gcd_amd.training.EDMSampling", "params": {"p_mean": 1.0, "p_std": 1.6}},
         loss_weighting_config={"target": "gcd_amd.training.EDMWeighting", "params": {"sigma_data": 1.0}},
@@ -105,7 +115,8 @@ def main():
         "frames": BT, "latent": [h, w], "forward_s": round(f, 3), "backward_s": round(b, 3), "adam_s": round(o, 3),
         "step_s": round(f + b + o, 3), "algorithmic_tflop": round(3 * tf_fwd, 2),
         "tflops": round(3 * tf_fwd / (f + b + o), 1), "loss_finite": finite,
-        "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
+        "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "engine": TR.TRAIN_ENGINE, "checkpoint": a.checkpoint, "clips": a.clips,
+        "hipgraph": _graph_mode(net)}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
