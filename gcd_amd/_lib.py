@@ -87,9 +87,8 @@ SIGNATURES = {
     "gcd_col2im_t3_f32": (_i, [_vp, _vp, _i64, _i64, _i, _i, _i, _vp]),
     "gcd_rowblock_sum_f32": (_i, [_vp, _i64, _i64, _i, _i64, _vp, _vp]),
     "gcd_groupnorm_bwd_scratch_floats": (_i64, [_i, _i64, _i64]),
-    "gcd_groupnorm_bwd": (_i, [_vp, _i64, _vp, _i64, _i, _i64, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i64, _vp, _i64,
-                               _vp]),
-    "gcd_layernorm_bwd": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp, _f, _vp, _i64, _vp, _vp, _vp]),
+    "gcd_groupnorm_bwd": (_i, [_vp, _i64, _vp, _i64, _i, _i64, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "gcd_layernorm_bwd": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp, _f, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "gcd_geglu_fwd_f32": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),
     "gcd_geglu_fwd_f16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),
     "gcd_geglu_fwd_bf16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),

@@ -574,7 +574,7 @@ def _gn_fwd(x, gamma, beta, rows_per_inst, eps, silu, dtype=_f16):
     return y16, stats, g32, b32
 
 
-def _gn_bwd(x, dy, stats, g32, b32, rows_per_inst, silu, dest=None):
+def _gn_bwd(x, dy, stats, g32, b32, rows_per_inst, silu, dest=None, dx_add=None):
     """dest (planned engine): (dgamma, dbeta) slots of the flat gradient buffer, written by one small kernel."""
     M, Cc = x.shape
     ninst = M // rows_per_inst
@@ -586,6 +586,7 @@ def _gn_bwd(x, dy, stats, g32, b32, rows_per_inst, silu, dest=None):
     check(lib.gcd_groupnorm_bwd(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), Cc, M, rows_per_inst,
                                 stats.data_ptr(), g32.data_ptr(), b32.data_ptr(), int(silu),
                                 AB.data_ptr(), scratch.data_ptr(), scratch.numel(), dx.data_ptr(), _ld(dx),
+                                0 if dx_add is None else dx_add.data_ptr(), 0 if dx_add is None else _ld(dx_add),
                                 _stream()),
           "gcd_groupnorm_bwd")
     if dest is not None and dest[0] is not None and dest[1] is not None:
@@ -604,7 +605,7 @@ def _ln_fwd(x, gamma, beta, eps, dtype=_f16):
     return y16, g32
 
 
-def _ln_bwd(x, dy, g32, eps, dest=None):
+def _ln_bwd(x, dy, g32, eps, dest=None, dx_add=None):
     """dest (planned engine): (dgamma, dbeta) slots of the flat gradient buffer (zeroed once per step): the kernel's
     atomics accumulate there directly."""
     M, Cc = x.shape
@@ -616,6 +617,7 @@ def _ln_bwd(x, dy, g32, eps, dest=None):
         dg, db = dgb[0], dgb[1]
     check(_lib.load().gcd_layernorm_bwd(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), M, Cc, g32.data_ptr(),
                                         eps, dx.data_ptr(), _ld(dx), dg.data_ptr(), db.data_ptr(),
+                                        0 if dx_add is None else dx_add.data_ptr(), 0 if dx_add is None else _ld(dx_add),
                                         _stream()), "gcd_layernorm_bwd")
     return dx, dg, db
 
@@ -724,10 +726,11 @@ class Fused(torch.autograd.Function):
                                                 _ld(dx), h.shape[0], h.shape[1] // 2, _stream()), "gcd_geglu_bwd_f32")
         elif norm[0] == "ln":
             x, g32 = saved
-            dx, dgamma, dbeta = _ln_bwd(x, da.contiguous(), g32, norm[1], norm_dest)
+            dx, dgamma, dbeta = _ln_bwd(x, da.contiguous(), g32, norm[1], norm_dest, getattr(ctx, "dx_add", None))
         else:
             x, g32, stats, b32 = saved
-            dx, dgamma, dbeta = _gn_bwd(x, da.contiguous(), stats, g32, b32, norm[1], norm[3], norm_dest)
+            dx, dgamma, dbeta = _gn_bwd(x, da.contiguous(), stats, g32, b32, norm[1], norm[3], norm_dest,
+                                        getattr(ctx, "dx_add", None))
         d_res = dy if has_res and nig[2] else None
         if want_vec and d_vec is None:
             d_vec = _colsum(dy, spec["rows_per_vec"])

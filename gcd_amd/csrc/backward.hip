@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy, int C,
     int64_t rows_per_inst, int rows_per_chunk, const float* __restrict__ stats,
     const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
-    const double* __restrict__ AB, float* __restrict__ dx, int64_t lddx) {
+    const double* __restrict__ AB, float* __restrict__ dx, int64_t lddx, const float* __restrict__ dx_add, int64_t ldadd) {
   // per-channel tables: mean, rstd, gamma, beta, s1 (group), s2 (group)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* tmu = (float*)smem_raw;
@@ -353,6 +353,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
       if (silu) dz *= dsilu_f(fmaf(ga[e], xh, be[e]));
       o[e] = rs[e] * (ga[e] * dz - g1[e] - xh * g2[e]);
     }
+    if (dx_add) o += *(const f32x4*)(dx_add + (base + r) * ldadd + c);      // (ABI v7: the other gradient path's addend)
     *(f32x4*)(dx + (base + r) * lddx + c) = o;
   }
 }
@@ -366,7 +367,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ dy, int64_t lddy,
                                                      int64_t M, int C, const float* __restrict__ gamma,
                                                      float eps, float* __restrict__ dx, int64_t lddx,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     const float* __restrict__ dx_add, int64_t ldadd) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwave = (int64_t)gridDim.x * 4;
@@ -427,6 +429,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = rstd * (dv[k][e] * gv[k][e] - m1 - xv[k][e] * m2);
+        if (dx_add) o += *(const f32x4*)(dx_add + m * ldadd + c);      // (ABI v7: the residual path's gradient)
         *(f32x4*)(dx + m * lddx + c) = o;
       }
     }
@@ -885,7 +888,8 @@ extern "C" int64_t gcd_groupnorm_bwd_scratch_floats(int C, int64_t M, int64_t ro
 extern "C" int gcd_groupnorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int C, int64_t M,
                                  int64_t rows_per_inst, const float* stats, const float* gamma,
                                  const float* beta, int silu, double* AB, float* scratch, int64_t scratch_floats,
-                                 float* dx, int64_t lddx, void* stream) {
+                                 float* dx, int64_t lddx, const float* dx_add, int64_t ld_add, void* stream) {
+  GCD_CHECK_ARG(!dx_add || ld_add % 4 == 0, "gcd_groupnorm_bwd: ld_add");
   GCD_CHECK_ARG(x && dy && stats && gamma && beta && AB && scratch && dx, "gcd_groupnorm_bwd: null pointer");
   GCD_CHECK_ARG(C > 0 && C % 32 == 0 && C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0,
                 "gcd_groupnorm_bwd: C=%d", C);
@@ -914,21 +918,22 @@ extern "C" int gcd_groupnorm_bwd(const float* x, int64_t ldx, const float* dy, i
   static GcdPerDeviceOnce attr_once;
   if (C * 24 > 48 * 1024) GCD_CHECK_HIP(attr_once.opt_in((const void*)gn_bwd_apply_kernel, 160 * 1024 - 512));
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(achunks, ninst), dim3(256), C * 24, s, x, ldx, dy, lddy, C,
-                     rows_per_inst, arpc, stats, gamma, beta, silu, AB, dx, lddx);
+                     rows_per_inst, arpc, stats, gamma, beta, silu, AB, dx, lddx, dx_add, ld_add);
   GCD_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int gcd_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t M, int C,
                                  const float* gamma, float eps, float* dx, int64_t lddx, float* dgamma_zeroed,
-                                 float* dbeta_zeroed, void* stream) {
+                                 float* dbeta_zeroed, const float* dx_add, int64_t ld_add, void* stream) {
+  GCD_CHECK_ARG(!dx_add || ld_add % 4 == 0, "gcd_layernorm_bwd: ld_add");
   GCD_CHECK_ARG(x && dy && gamma && dx && dgamma_zeroed && dbeta_zeroed, "gcd_layernorm_bwd: null pointer");
   GCD_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 1280 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && M > 0,
                 "gcd_layernorm_bwd: C=%d (multiple of 4, <= 1280)", C);
   int64_t blocks = (M + 3) / 4;
   if (blocks > 768) blocks = 768;      // 3 workgroups per CU; every workgroup ends with 2 C atomics
   hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy,
-                     M, C, gamma, eps, dx, lddx, dgamma_zeroed, dbeta_zeroed);
+                     M, C, gamma, eps, dx, lddx, dgamma_zeroed, dbeta_zeroed, dx_add, ld_add);
   GCD_CHECK_LAUNCH();
   return 0;
 }

@@ -138,9 +138,11 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(const float* __restrict_
       const f32x4 d = *(const f32x4*)(xs + m * lds_ + c) - *(const f32x4*)(xt + m * ldt + c);
       part += g[0] * d[0] + g[1] * d[1] + g[2] * d[2] + g[3] * d[3];
     }
-    f32x4 o = a * g;
-    if (acc_xs) o += *(const f32x4*)(dxs + m * lddxs + c);
-    *(f32x4*)(dxs + m * lddxs + c) = o;
+    if (dxs) {
+      f32x4 o = a * g;
+      if (acc_xs) o += *(const f32x4*)(dxs + m * lddxs + c);
+      *(f32x4*)(dxs + m * lddxs + c) = o;
+    }
     *(f32x4*)(dxt + m * lddxt + c) = (1.0f - a) * g;
   }
   if (dalpha) {
@@ -387,7 +389,7 @@ extern "C" int gcd_blend_fwd_f32(const float* xs, int64_t ld_s, const float* xt,
 extern "C" int gcd_blend_bwd_f32(const float* dy, int64_t ld_dy, const float* xs, int64_t ld_s, const float* xt, int64_t ld_t,
                                  const float* alpha, int64_t M, int C, int64_t rows_per_frame, float* d_xs, int64_t ld_dxs,
                                  int accumulate_xs, float* d_xt, int64_t ld_dxt, float* d_alpha_zeroed, void* stream) {
-  T_CHECK_ARG(dy && alpha && d_xs && d_xt && (!d_alpha_zeroed || (xs && xt)), "gcd_blend_bwd_f32: null pointer");
+  T_CHECK_ARG(dy && alpha && d_xt && (!d_alpha_zeroed || (xs && xt)), "gcd_blend_bwd_f32: null pointer");   // (d_xs optional)
   T_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && rows_per_frame > 0 && M % rows_per_frame == 0 && ld_dy % 4 == 0 &&
                   ld_dxs % 4 == 0 && ld_dxt % 4 == 0 && (!d_alpha_zeroed || (ld_s % 4 == 0 && ld_t % 4 == 0)),
               "gcd_blend_bwd_f32: M=%lld C=%d rows=%lld", (long long)M, C, (long long)rows_per_frame);

@@ -74,9 +74,13 @@ def _fused_fwd(kind, x, params, geo=None, norm=None, residual=None, rowvec=None)
     return y, ctx
 
 
-def _fused_bwd(plan: "TrainPlan", ctx: _Ctx, dy: torch.Tensor, need_x: bool = True, need_vec: bool = True):
-    """-> (dx | None, d_vec | None).  Parameter gradients go to `plan.sink`."""
+def _fused_bwd(plan: "TrainPlan", ctx: _Ctx, dy: torch.Tensor, need_x: bool = True, need_vec: bool = True, dx_add=None):
+    """-> (dx | None, d_vec | None).  Parameter gradients go to `plan.sink`.  dx_add: another gradient of the same input
+    (the residual branch's), added to dx — inside the LayerNorm / GroupNorm backward kernel when the node has one."""
     has_res, has_vec, has_bias = ctx.has
+    norm = ctx.spec.get("norm")
+    fused_add = dx_add is not None and norm is not None and norm[0] in ("ln", "gn")
+    ctx.dx_add = dx_add.contiguous() if fused_add else None
     params = ctx.params
     want = [p is not None and p.requires_grad for p in params]
     gm = ctx.norm_mod
@@ -91,6 +95,8 @@ def _fused_bwd(plan: "TrainPlan", ctx: _Ctx, dy: torch.Tensor, need_x: bool = Tr
     finally:
         A._GRAD_SINK = None
     dx, d_vec, dgamma, dbeta = out[1], out[3], out[4], out[5]
+    if dx_add is not None and not fused_add and dx is not None:
+        dx = dx.add_(dx_add)
     if want_norm:
         plan.sink(gm.weight, dgamma)
         plan.sink(gm.bias, dbeta)
@@ -271,22 +277,21 @@ class _ResUnit:
     def bwd(self, saved, dy):
         plan, rb = self.plan, self.rb
         c1, cs, c2, c3, c4, xs, xt, HW = saved
-        d_xs, d_xt = plan.blend_bwd(rb.time_mixer, dy, xs, xt, HW)
+        dy = dy.contiguous()
+        # y = a xs + (1 - a) xt and xt = t3(...) + xs: the gradient that reaches xs directly is a dy + (1 - a) dy = dy
+        d_xt = plan.blend_bwd(rb.time_mixer, dy, xs, xt, HW, want_xs=False)[1]
         del xs, xt
         # time_stack: xt = t3(gn(h)) + xs ; h = t3(gn(xs)) + et
         dh, _ = _fused_bwd(plan, c4, d_xt)
-        _add(d_xs, d_xt)
         del d_xt
-        dx1, d_et = _fused_bwd(plan, c3, dh)
-        _add(d_xs, dx1)
-        del dh, dx1
+        d_xs, d_et = _fused_bwd(plan, c3, dh, dx_add=dy)
+        del dh
         # 2-D: xs = c3(gn(h)) + skip ; h = c3(gn(x)) + e2d
         dh, _ = _fused_bwd(plan, c2, d_xs)
-        dx, d_e2d = _fused_bwd(plan, c1, dh, need_x=True)
-        del dh
         if cs is None:
-            dx = _add(dx, d_xs)
+            dx, d_e2d = _fused_bwd(plan, c1, dh, dx_add=d_xs)
         else:
+            dx, d_e2d = _fused_bwd(plan, c1, dh)
             dsk, _ = _fused_bwd(plan, cs, d_xs)
             dx = _add(dx, dsk)
         plan.emb_grads[self.idx] = (d_e2d, d_et)
@@ -313,8 +318,8 @@ class _AttnUnit:
         """d = gradient of y = ff(ln(x)) + x -> gradient of x (a fresh tensor when d must survive: it does not here)."""
         plan = self.plan
         du, _ = _fused_bwd(plan, cb, d)
-        dx, _ = _fused_bwd(plan, ca, du)
-        return _add(dx, d)
+        dx, _ = _fused_bwd(plan, ca, du, dx_add=d)
+        return dx
 
     def fwd(self, x, H, W, save: bool):
         plan, tr = self.plan, self.tr
@@ -374,10 +379,8 @@ class _AttnUnit:
             do, d_ca_t = _fused_bwd(plan, co2, d_xm2)
             dqkv = A.TemporalAttention.backward(ta, do)[0]
             del do
-            dx, _ = _fused_bwd(plan, cq2, dqkv)
-            del dqkv
-            d_xm1 = _add(dx, d_xm2)
-            del d_xm2
+            d_xm1, _ = _fused_bwd(plan, cq2, dqkv, dx_add=d_xm2)
+            del dqkv, d_xm2
             d_xm0 = self._ff_bwd(cfia, cfib, d_xm1)
             del d_xm1
             d_pos = plan.rowblock_sum(d_xm0, HW)           # xm0 = h2 + pos per frame
@@ -388,14 +391,12 @@ class _AttnUnit:
             do, d_ca_s = _fused_bwd(plan, co1, d_h1)
             dqkv = A.SpatialAttention.backward(sa, do)[0]
             del do
-            dx, _ = _fused_bwd(plan, cq1, dqkv)
-            del dqkv
-            dh = _add(dx, d_h1)
-            del d_h1
+            dh, _ = _fused_bwd(plan, cq1, dqkv, dx_add=d_h1)
+            del dqkv, d_h1
             grads.append((d_ca_s, d_ca_t, d_pos))
-        dx, _ = _fused_bwd(plan, ctxs[0], dh)
+        dx, _ = _fused_bwd(plan, ctxs[0], dh, dx_add=dy)
         plan.attn_grads[self.idx] = grads[::-1]
-        return _add(dx, dy)
+        return dx
 
 
 class _ConvUnit:
@@ -772,16 +773,17 @@ class TrainPlan:
                                                              y.stride(0), _stream()), "gcd_blend_fwd_f32")
         return y
 
-    def blend_bwd(self, blender, dy, xs, xt, rows):
-        """-> (d_xs, d_xt) fresh tensors; the mix factor's gradient partials accumulate in the step's arena."""
+    def blend_bwd(self, blender, dy, xs, xt, rows, want_xs: bool = True):
+        """-> (d_xs | None, d_xt) fresh tensors; the mix factor's gradient partials accumulate in the step's arena."""
         a, live, slot, _ = self._alpha(blender)
         dy = dy.contiguous()
-        d_xs, d_xt = torch.empty_like(dy), torch.empty_like(dy)
+        d_xs, d_xt = (torch.empty_like(dy) if want_xs else None), torch.empty_like(dy)
         want = blender.merge_strategy != "fixed" and blender.mix_factor.requires_grad
         dal = self._dalpha[slot] if want else None
         _lib.check_train(_lib.load_train().gcd_blend_bwd_f32(
             dy.data_ptr(), dy.stride(0), xs.data_ptr(), xs.stride(0), xt.data_ptr(), xt.stride(0), a.data_ptr(),
-            dy.shape[0], dy.shape[1], rows, d_xs.data_ptr(), d_xs.stride(0), 0, d_xt.data_ptr(), d_xt.stride(0),
+            dy.shape[0], dy.shape[1], rows, 0 if d_xs is None else d_xs.data_ptr(), dy.stride(0), 0, d_xt.data_ptr(),
+            d_xt.stride(0),
             0 if dal is None else dal.data_ptr(), _stream()), "gcd_blend_bwd_f32")
         return d_xs, d_xt
 

@@ -333,11 +333,13 @@ int64_t gcd_groupnorm_bwd_scratch_floats(int C, int64_t M, int64_t rows_per_inst
 int gcd_groupnorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int C, int64_t M,
                       int64_t rows_per_inst, const float* stats, const float* gamma, const float* beta,
                       int silu, double* AB, float* scratch, int64_t scratch_floats, float* dx, int64_t lddx,
-                      void* stream);
-/* LayerNorm backward (rows of C <= 1280): dx, and dgamma / dbeta accumulated into zeroed [C] buffers. */
+                      const float* dx_add, int64_t ld_add, void* stream);
+/* LayerNorm backward (rows of C <= 1280): dx, and dgamma / dbeta accumulated into zeroed [C] buffers.
+ * dx_add (ABI v7, optional, both norm backwards): a second gradient of the same tensor (the residual branch's) added to dx
+ * on the way out — saves an elementwise add pass per norm in the planned fine-tune engine. */
 int gcd_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t M, int C,
                       const float* gamma, float eps, float* dx, int64_t lddx, float* dgamma_zeroed,
-                      float* dbeta_zeroed, void* stream);
+                      float* dbeta_zeroed, const float* dx_add, int64_t ld_add, void* stream);
 /* GEGLU on the fp32 projection h = [value | gate] [M, 2H] (attention.py:87-97): out = value*gelu(gate)
  * (exact erf) and its backward.                                                                      */
 int gcd_geglu_fwd_f32(const float* h, int64_t ldh, float* out, int64_t ldo, int64_t M, int H, void* stream);

@@ -60,7 +60,7 @@ int gcd_train_pack_weights(const gcd_pack_entry* table_dev, int n_entries, int t
 
 /* ---- AlphaBlender (util.py:358-369) and its backward --------------------------------------------------------------------
  * y = a xs + (1 - a) xt with a per frame of rows_per_frame token rows (fp32, C % 4 == 0, leading dimensions % 4 == 0).
- * Backward: d_xs (+)= a dy (accumulate_xs adds onto d_xs), d_xt = (1 - a) dy, and — when d_alpha_zeroed is given —
+ * Backward: d_xs (+)= a dy (accumulate_xs adds onto d_xs; d_xs may be NULL), d_xt = (1 - a) dy, and — when d_alpha_zeroed is given —
  * d_alpha[frame] += sum dy (xs - xt) (atomic partial sums onto a buffer the caller zeroed). */
 int gcd_blend_fwd_f32(const float* xs, int64_t ld_s, const float* xt, int64_t ld_t, const float* alpha, int64_t M, int C,
                       int64_t rows_per_frame, float* y, int64_t ld_y, void* stream);
