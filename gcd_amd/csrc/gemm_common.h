@@ -281,6 +281,30 @@ __device__ __forceinline__ void gcd_stage_geglu_half(const GcdAcc16& acc, int j,
   }
 }
 
+#ifdef GCD_ABLATION_BUILD
+// Ablation forms of the GEGLU staging (gemm_p8 VAR bits 128 / 256, tools/gemm_bench): ABL 1 = value * gate without the GELU
+// polynomial, ABL 2 = no arithmetic at all (the value, converted) — how much of the serial tile epilogue is VALU.
+template <int ABL>
+__device__ __forceinline__ void gcd_stage_geglu_half_abl(const GcdAcc16& acc, int j, const float* lb, char* stage, int lane) {
+  const int r15 = lane & 15, q = lane >> 4;
+  const float* lbl = lb + 4 * q;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const f32x4 ba = *(const f32x4*)(lbl + 32 * i);
+    const f32x4 bg = *(const f32x4*)(lbl + 32 * i + 16);
+#pragma unroll
+    for (int th = 0; th < 2; ++th) {
+      f16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        o[e] = ABL == 2 ? (f16)acc[2 * i][2 * j + th][e]
+                        : (f16)((acc[2 * i][2 * j + th][e] + ba[e]) * (acc[2 * i + 1][2 * j + th][e] + bg[e]));
+      *(f16x4*)(stage + (16 * th + r15) * GCD_EPI_ROW_F16 + (16 * i + 4 * q) * 2) = o;
+    }
+  }
+}
+#endif
+
 // fp16 output without residuals: token half j -> `stage` as fp16 [32][160] rows of GCD_EPI_ROW_H160 bytes
 #define GCD_EPI_ROW_H160 336
 __device__ __forceinline__ void gcd_stage_f16_half(const GcdAcc32& acc, int j, const float* lb, float sa, char* stage,
@@ -440,7 +464,7 @@ __device__ __forceinline__ void gcd_epi_f32_rows_full(const GemmK& p, ACC& acc, 
 // ([32][80] + 16 B row pad, twice) and leave as 16-byte pieces of 160-byte row segments: 6.4 rows per store
 // instruction instead of 32 rows x 16 B straight from the accumulator layout, and half as many store
 // instructions (measured -3..-7 % per GEGLU launch, profiles/r01q_gemm_bench_rows.txt).
-template <typename ACC>
+template <typename ACC, int ABL = 0>
 __device__ __forceinline__ void gcd_epi_geglu_rows_full(const GemmK& p, ACC& acc, int m_base,
                                                         int n_base, int lane, const float* lb, char* stage) {
   // row-major [M, N/2], or tile-blocked: tile (tm, tn) = one contiguous [256][160] block (out_blocked)
@@ -455,7 +479,11 @@ __device__ __forceinline__ void gcd_epi_geglu_rows_full(const GemmK& p, ACC& acc
   // one 32-token half at a time (5.5 KB of stage): the stores of half 0 drain under the GELU of half 1
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    gcd_stage_geglu_half(acc, j, lb, stage, lane);
+#ifdef GCD_ABLATION_BUILD
+    if constexpr (ABL != 0) gcd_stage_geglu_half_abl<ABL>(acc, j, lb, stage, lane);
+    else
+#endif
+      gcd_stage_geglu_half(acc, j, lb, stage, lane);
 #pragma unroll
     for (int it = 0; it < 5; ++it) {
       const int tt = it * 64 + lane;

@@ -84,6 +84,7 @@ static_assert(P8_HALO_W0 + 2 * P8_W_BYTES <= P8_BIAS0, "halo layout must fit bel
 //   the LDS-only barrier   8 no cross-tile prefetch   16 / 32 / 64 flip the mode's default of: ds_reads before the
 //   LDS-DMA of a phase (PLAIN default; the conv modes stage first, for their tap arithmetic) / no s_setprio around the
 //   MFMA clusters (PLAIN default) / tile walk in groups of 8 instead of 4 M-tiles (PLAIN default).
+//   128 / 256 (round 5): GEGLU epilogue without the GELU polynomial / without any arithmetic (profiles/r05_geglu_epilogue_valu.txt)
 //   Measured (profiles/r04j_p8_variants.txt, two runs of 15): with all three L0 GEGLU 612-617 -> 500-509 us, L1 GEGLU
 //   400-403 -> 376-381, L2 GEGLU 337-346 -> 321-327; FF-out / proj / q|k|v within +-1 %.
 // EPI: which full-tile fast path of the epilogue this instantiation carries (the generic direct path is always there,
@@ -687,7 +688,12 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmK p) {
         constexpr bool E_GEGLU = EPI == 0 || EPI == 1, E_F16 = EPI == 0 || EPI == 2, E_F32 = EPI == 0 || EPI == 3,
                        E_R2 = EPI == 0 || EPI == 4, E_R2H = EPI == 0 || EPI == 5;
         if (E_GEGLU && full && p.out_kind == GCD_OUT_GEGLU && (p.ldo & 7) == 0 && !p.out_blocked) {
-          gcd_epi_geglu_rows_full(p, acc, wm_base, wn_base, elane, lb, e_stage);
+#ifdef GCD_ABLATION_BUILD
+          if constexpr ((VAR & 128) != 0) gcd_epi_geglu_rows_full<GcdAcc16, 1>(p, acc, wm_base, wn_base, elane, lb, e_stage);
+          else if constexpr ((VAR & 256) != 0) gcd_epi_geglu_rows_full<GcdAcc16, 2>(p, acc, wm_base, wn_base, elane, lb, e_stage);
+          else
+#endif
+            gcd_epi_geglu_rows_full(p, acc, wm_base, wn_base, elane, lb, e_stage);
           nst = 10;
         } else if (E_F16 && full && p.out_kind == GCD_OUT_F16 && !p.R1 && !p.R2 && !p.frame_alpha && (p.ldo & 7) == 0) {
           gcd_epi_f16_rows_full(p, acc, wm_base, wn_base, elane, lb, e_stage);
@@ -851,7 +857,7 @@ int gcd_gemm_p8_launch(const GemmK& k, int mode, bool persist, hipStream_t s) {
   }
   {   // GCD_TUNE_GEMM_IMPL = 64 + ablation bits (PLAIN)
     const int var = gcd_tune_get(GCD_TUNE_GEMM_IMPL) - 64;
-    if (var > 0 && var < 128 && mode == GCD_GEMM_PLAIN && !k.colstats && !k.operand_bf16) {
+    if (var > 0 && var <= 256 + 2 && mode == GCD_GEMM_PLAIN && !k.colstats && !k.operand_bf16) {
       const int epi = k.out_kind == GCD_OUT_GEGLU ? 1 : (k.out_kind == GCD_OUT_F16 && !k.R1 && !k.R2 && !k.frame_alpha) ? 2 : 3;
       if (k.R2) return -1 + 0 * gcd_tune_get(0);   // (no ablation instantiations of the two-residual path)
 #define P8_ABL(V)                                                             \
@@ -871,6 +877,10 @@ int gcd_gemm_p8_launch(const GemmK& k, int mode, bool persist, hipStream_t s) {
         P8_ABL(80)
         P8_ABL(96)
         P8_ABL(112)
+        P8_ABL(128)        // GEGLU epilogue without the GELU polynomial
+        P8_ABL(256)        // GEGLU epilogue without any arithmetic
+        P8_ABL(128 + 2)    // ... and without the K loop: the epilogues alone
+        P8_ABL(256 + 2)
         default: break;
       }
 #undef P8_ABL

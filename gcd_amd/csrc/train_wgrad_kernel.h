@@ -19,7 +19,23 @@ typedef short v4s __attribute__((__vector_size__(4 * sizeof(short))));
 namespace gcd_wgrad {
 
 constexpr int TN = 128, TK = 128;              // output tile
-constexpr int PITCH = TN * 2 + 16;             // bytes per LDS row: 128 16-bit elements + 16 B pad (TN == TK)
+// LDS rows of 128 16-bit elements (TN == TK).  Round 5: 256-byte rows, the eight 32-byte segments of a row XOR-swizzled by
+// the row, instead of 272-byte padded rows.  ds_read_b64_tr_b16 is serviced in groups of 32 lanes over 64 banks of 4 B
+// (MI355X_MICROARCH.md, LDS): a group is two 4-row x 32-byte blocks (rows r .. r + 3 and r + 8 .. r + 11 of one 16-column
+// block).  With 272-byte rows consecutive rows sit 16 bytes apart in bank space, so every block overlaps itself 2-way —
+// every transposing read took 2x its LDS cycles in a kernel that is LDS-bound (0.5 KB of fragments per MFMA).  No uniform
+// row pitch separates all eight row segments (8 rows further is always +0 or +128 bytes); the swizzle
+//     segment' = segment ^ ((row & 3) | ((row >> 3) & 1) << 2)
+// gives the eight rows of a group eight different segments: conflict-free.  GCD_WGRAD_PAD=1 keeps the padded layout (A/B).
+#ifndef GCD_WGRAD_PAD
+#define GCD_WGRAD_PAD 0
+#endif
+constexpr int PITCH = GCD_WGRAD_PAD ? TN * 2 + 16 : TN * 2;
+__device__ __forceinline__ int swz_seg(int row) { return GCD_WGRAD_PAD ? 0 : ((row & 3) | (((row >> 3) & 1) << 2)); }
+// byte offset of the 16-byte chunk `chunk` (0 .. 15) of tile row `row`
+__device__ __forceinline__ int lds_chunk_off(int row, int chunk) {
+  return row * PITCH + ((((chunk >> 1) ^ swz_seg(row)) << 5) | ((chunk & 1) << 4));
+}
 // LDS of a launch with TM tokens per step: [buffer][operand][TM rows]
 constexpr int smem_bytes(int TM) { return 2 * 2 * TM * PITCH; }
 
@@ -28,7 +44,8 @@ constexpr int smem_bytes(int TM) { return 2 * 2 * TM * PITCH; }
 // of the 4 x 16 block; it receives column i (profiles/r04_probe_ds_read_tr_b16.txt).
 __device__ __forceinline__ f16x8 frag_tr(const char* tile, int r0, int c0, int lane) {
   const int g = lane >> 4, i = lane & 15;
-  const char* p = tile + (r0 + 8 * g + (i >> 2)) * PITCH + (c0 + 4 * (i & 3)) * 2;
+  const int row = r0 + 8 * g + (i >> 2);          // (row + 4 has the same swizzle: bits 0-1 and bit 3 are unchanged)
+  const char* p = tile + row * PITCH + ((((c0 >> 4) ^ swz_seg(row)) << 5) | ((i & 3) << 3));
   const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GCD_AS3 v4s*)(p));
   const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GCD_AS3 v4s*)(p + 4 * PITCH));
   const f16x4 l4 = __builtin_bit_cast(f16x4, lo), h4 = __builtin_bit_cast(f16x4, hi);
@@ -69,8 +86,8 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const f16* __restrict__ d
     char* b = a + TILE_BYTES;
 #pragma unroll
     for (int h = 0; h < NP; ++h) {
-      *(f16x8*)(a + (srow + 16 * h) * PITCH + schunk * 16) = ra[h];
-      *(f16x8*)(b + (srow + 16 * h) * PITCH + schunk * 16) = rb[h];
+      *(f16x8*)(a + lds_chunk_off(srow + 16 * h, schunk)) = ra[h];
+      *(f16x8*)(b + lds_chunk_off(srow + 16 * h, schunk)) = rb[h];
     }
   };
   f32x4 acc[4][4];
