@@ -63,6 +63,31 @@ def test_gemm_desc_layout_matches_header(tmp_path):
     assert int(out["sizeof"]) == ctypes.sizeof(_lib.GemmDesc)
 
 
+@pytest.mark.parametrize("cname,pyname", [("gcd_pack_entry", "PackEntry"), ("gcd_smallm_problem", "SmallmProblem")])
+def test_train_table_structs_match_header(tmp_path, cname, pyname):
+    """ctypes mirrors of the device-table structs of include/gcd_amd_train.h (the multi-tensor weight pack, the grouped
+    few-row Linears) have the C structs' offsets and sizes (checked with gcc)."""
+    import shutil
+    import subprocess
+    from gcd_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    cls = getattr(_lib, pyname)
+    fields = [f[0] for f in cls._fields_]
+    src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT / "include" / "gcd_amd_train.h"}"',
+           'int main(void) {']
+    src += [f'  printf("{n} %zu\\n", offsetof({cname}, {n}));' for n in fields]
+    src += [f'  printf("sizeof %zu\\n", sizeof({cname}));', '  return 0;', '}']
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-o", str(exe), str(c)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)]).decode().splitlines())
+    for n in fields:
+        assert int(out[n]) == getattr(cls, n).offset, n
+    assert int(out["sizeof"]) == ctypes.sizeof(cls)
+
+
 def test_ops_refuse_cpu_tensors_and_bad_args():
     from gcd_amd import _lib, ops
     a = torch.zeros(64, 64, dtype=torch.float16)

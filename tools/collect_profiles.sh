@@ -30,10 +30,16 @@ python tools/pmc_gemm_shapes.py $OUT/launches.json $F $W $H > $OUT/gemm_shape_tr
     -d $OUT/pmc_sq2 -o p -- python $ROOT/bench.py --steps 1 --warmup 1 --repeats 1 --no-cpu-baseline > $OUT/pmc_sq2.log 2>&1)
 (cd tools && python pmc_sq2.py $(find $OUT/pmc_sq2 -name "*counter_collection.csv" | head -1) > $OUT/sq_valu_mix.txt)
 tools/gemm_bench full 5 > $OUT/gemm_bench_rows.txt 2>&1
-for dt in fp16 bf16; do python tools/train_step_bench.py --steps 3 --dtype $dt > $OUT/train_step_$dt.json 2>/dev/null; done
-(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/trace_train -o t -- python $ROOT/tools/train_step_bench.py --steps 2 \
+# the fine-tune step (round 5: planned engine by default; the autograd engine and forced checkpointing beside it)
+for dt in fp16 bf16; do python tools/train_step_bench.py --steps 4 --dtype $dt > $OUT/train_step_$dt.json 2>/dev/null; done
+python tools/train_step_bench.py --steps 4 --checkpoint on > $OUT/train_step_fp16_checkpointed.json 2>/dev/null
+GCD_TRAIN_ENGINE=autograd python tools/train_step_bench.py --steps 4 > $OUT/train_step_fp16_autograd_engine.json 2>/dev/null
+GCD_TRAIN_GRAPH=1 python tools/train_step_bench.py --steps 8 > $OUT/train_step_fp16_hipgraph.json 2>/dev/null
+for c in 4 8; do python tools/train_step_bench.py --steps 3 --clips $c > $OUT/train_step_fp16_${c}clips.json 2>/dev/null; done
+python tools/train_step_bench.py --steps 3 --clips 8 --checkpoint on > $OUT/train_step_fp16_8clips_checkpointed.json 2>/dev/null
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/trace_train -o t -- python $ROOT/tools/train_step_bench.py --steps 9 \
     > /dev/null 2>&1)
-python tools/rocpd_stats.py $(find $OUT/trace_train -name "*_results.db" | head -1) > $OUT/train_kernel_stats.txt
+python tools/rocpd_stats.py $(find $OUT/trace_train -name "*_results.db" | head -1) --steps 10 > $OUT/train_kernel_stats.txt
 # keep the summaries only: gpurun merges at most 64 MiB back
 rm -rf $OUT/trace $OUT/trace_train $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_TCC_HIT_sum $OUT/pmc_sq $OUT/pmc_sq2
 du -sh $ROOT/gpurun_out
