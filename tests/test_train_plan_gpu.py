@@ -318,3 +318,47 @@ def test_planned_engine_many_frames(gpu):
     den = sum(float(v.double().pow(2).sum()) for v in ga.values())
     print(f"40 frames: output {rel_l2(op, oa):.2e}, gradients {(num / den) ** 0.5:.2e}")
     assert (num / den) ** 0.5 < 5e-3
+
+
+def test_planned_engine_gradient_accumulation(gpu):
+    """Two micro-batches without zero_grad() in between (accumulate_grad_batches, main.py:950): the second backward finds
+    the plan's own views in .grad and ADDS — equal to the sum of the two batches' separate gradients; zero_grad() (set to
+    None) starts over."""
+    from gcd_amd import autograd_ops as A
+    from gcd_amd.train_plan import unet_forward_planned
+    net = _tiny(gpu, salt=13)
+    cfg = O.TINY
+    g = torch.Generator().manual_seed(51)
+    T, H, W = 4, 8, 8
+
+    def batch():
+        return (torch.randn(2 * T, 8, H, W, generator=g).to(gpu), torch.linspace(-1.0, 1.0, 2 * T).to(gpu),
+                torch.randn(2 * T, 1, cfg.context_dim, generator=g).to(gpu),
+                torch.randn(2 * T, cfg.adm_in_channels + cfg.aux_emb_dim, generator=g).clamp(-1, 1).to(gpu),
+                torch.randn(2 * T, 4, H, W, generator=g).to(gpu))
+    ioi = torch.zeros(2, T, device=gpu)
+    b1, b2 = batch(), batch()
+    A.PACK.clear()
+
+    def run(b):
+        out = unet_forward_planned(net, b[0], b[1], b[2], b[3], T, ioi, use_checkpoint=True)
+        ((out - b[4]) ** 2).mean().mul(64.0).backward()
+    sep = []
+    for b in (b1, b2):
+        for p in net.parameters():
+            p.grad = None
+        run(b)
+        sep.append({n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None})
+    for p in net.parameters():
+        p.grad = None
+    run(b1)
+    run(b2)          # no zero_grad(): accumulates
+    torch.cuda.synchronize()
+    worst = 0.0
+    for n, p in net.named_parameters():
+        if n in sep[0]:
+            want = sep[0][n] + sep[1][n]
+            if want.numel() >= 64 and float(want.abs().max()) > 0:
+                worst = max(worst, rel_l2(p.grad, want))
+    print(f"accumulated vs summed gradients: worst {worst:.1e}")
+    assert worst < 1e-3
