@@ -99,7 +99,7 @@ SIGNATURES = {
     "gcd_attn_temporal_bwd": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
     "gcd_cast_scale_f32_f16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _f, _vp]),
     "gcd_cast_f32_bf16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),
-    "gcd_cast_colsum_f32": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _i64, _vp, _i, _vp]),
+    "gcd_cast_colsum_f32": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _i64, _vp, _i, _vp, _vp]),
     "gcd_cast_f16_bf16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _vp]),
     "gcd_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "gcd_adam_step_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _f, _vp]),

@@ -219,7 +219,7 @@ def _gemm(a16, w16, out, **kw):
     return ops.gemm(a16, w16, out, operand_bf16=a16.dtype == _bf16, workspace=_train_ws(a16.device), sched=2, **kw)
 
 
-def _cast16_colsum(dy32: torch.Tensor, dtype: torch.dtype, rows_per_block: Optional[int], out_sums=None):
+def _cast16_colsum(dy32: torch.Tensor, dtype: torch.dtype, rows_per_block: Optional[int], out_sums=None, total=None):
     """(dy16, sums [M / rows, N]): the incoming gradient rounded for the GEMMs and its row-block column sums (bias /
     per-frame-vector gradients) in one pass (gcd_cast_colsum_f32); plain cast when no sums are wanted or the width
     is not a multiple of 8."""
@@ -230,8 +230,10 @@ def _cast16_colsum(dy32: torch.Tensor, dtype: torch.dtype, rows_per_block: Optio
     # out_sums (planned engine): the bias's own slot of the flat gradient buffer, zeroed once per step — the kernel's
     # atomics land there directly (no fill, no copy)
     sums = out_sums if out_sums is not None else _zeros(M // rows_per_block, N, dy32.device)
+    # total (planned engine): the bias's slot, receiving the sum over all row blocks in the same pass
     check(_lib.load().gcd_cast_colsum_f32(dy32.data_ptr(), _ld(dy32), y.data_ptr(), _ld(y), M, N, rows_per_block,
-                                          sums.data_ptr(), int(dtype == _bf16), _stream()), "gcd_cast_colsum_f32")
+                                          sums.data_ptr(), int(dtype == _bf16), 0 if total is None else total.data_ptr(),
+                                          _stream()), "gcd_cast_colsum_f32")
     return y, sums
 
 
@@ -706,12 +708,14 @@ class Fused(torch.autograd.Function):
         norm_dest = getattr(ctx, "norm_dest", None)
         if (want_db or want_vec) and _FUSE_DY_SUMS and dy.shape[1] % 8 == 0:
             rows = spec["rows_per_vec"] if want_vec else dy.shape[0]
+            both = want_vec and want_db and bias_dest is not None
             dy16, sums = _cast16_colsum(dy, _dt(GRAD_DTYPE), rows,
-                                        bias_dest.view(1, -1) if bias_dest is not None and want_db and not want_vec else None)
+                                        bias_dest.view(1, -1) if bias_dest is not None and want_db and not want_vec else None,
+                                        bias_dest if both else None)
             if want_vec:
                 d_vec = sums
             if want_db:
-                db_pre = sums.sum(0) if want_vec else sums[0]
+                db_pre = bias_dest if both else (sums.sum(0) if want_vec else sums[0])
         da, dps = _contract_bwd(kind, dy, a16, params, geo, need_da, need_dw, dy16, db_pre)
         dgamma = dbeta = None
         if norm is None:

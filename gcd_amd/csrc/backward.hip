@@ -669,7 +669,7 @@ template <bool BF>
 __global__ __launch_bounds__(256) void cast_colsum_kernel(const float* __restrict__ x, int64_t ldx,
                                                           unsigned short* __restrict__ y, int64_t ldy,
                                                           int64_t rows_per_block, int chunks, int rows_per_chunk, int C,
-                                                          float* __restrict__ sums) {
+                                                          float* __restrict__ sums, float* __restrict__ total) {
   __shared__ float red[32][65];
   const int t = threadIdx.x, cg = t & 7, rl = t >> 3;
   const int c = blockIdx.x * 64 + cg * 8;
@@ -708,6 +708,7 @@ __global__ __launch_bounds__(256) void cast_colsum_kernel(const float* __restric
 #pragma unroll
     for (int r = 0; r < 32; ++r) s0 += red[r][t];
     atomicAdd(sums + (int64_t)blk * C + blockIdx.x * 64 + t, s0);
+    if (total) atomicAdd(total + blockIdx.x * 64 + t, s0);      // ABI v7: the sum over ALL row blocks too (the bias gradient)
   }
 }
 
@@ -1021,7 +1022,8 @@ extern "C" int gcd_cast_f32_bf16(const float* x, int64_t ldx, void* y16, int64_t
 }
 
 extern "C" int gcd_cast_colsum_f32(const float* x, int64_t ldx, void* y16, int64_t ldy, int64_t M, int C,
-                                   int64_t rows_per_block, float* sums_zeroed, int to_bf16, void* stream) {
+                                   int64_t rows_per_block, float* sums_zeroed, int to_bf16, float* total_zeroed,
+                                   void* stream) {
   GCD_CHECK_ARG(x && y16 && sums_zeroed && M > 0 && C > 0 && C % 8 == 0 && ldx % 4 == 0 && ldy % 8 == 0 &&
                     (((uintptr_t)x | (uintptr_t)y16) & 15) == 0,
                 "gcd_cast_colsum_f32: bad args (C=%d must be a multiple of 8, 16-byte aligned rows)", C);
@@ -1039,10 +1041,10 @@ extern "C" int gcd_cast_colsum_f32(const float* x, int64_t ldx, void* y16, int64
   const dim3 grid(colb, (unsigned)(nblk * chunks));
   if (to_bf16)
     hipLaunchKernelGGL(cast_colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, (unsigned short*)y16,
-                       ldy, rows_per_block, (int)chunks, rpc, C, sums_zeroed);
+                       ldy, rows_per_block, (int)chunks, rpc, C, sums_zeroed, total_zeroed);
   else
     hipLaunchKernelGGL(cast_colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, (unsigned short*)y16,
-                       ldy, rows_per_block, (int)chunks, rpc, C, sums_zeroed);
+                       ldy, rows_per_block, (int)chunks, rpc, C, sums_zeroed, total_zeroed);
   GCD_CHECK_LAUNCH();
   return 0;
 }

@@ -475,6 +475,20 @@ class TrainPlan:
         self._table_cache: Dict[tuple, tuple] = {}
         self._pos_in: Dict[tuple, torch.Tensor] = {}
         self._units = self._build_units()
+        self._blenders = [rb.time_mixer for rb in self.res_blocks] + [tr.time_mixer for tr in self.transformers]
+        self._blender_slot = {id(b): i for i, b in enumerate(self._blenders)}
+        self._blender_fixed = torch.tensor([b.merge_strategy == "fixed" for b in self._blenders], device=dev)
+        self._blender_with_images = torch.tensor([b.merge_strategy == "learned_with_images" for b in self._blenders],
+                                                 device=dev)
+        # positions of the (scalar) mix factors in the flat gradient buffer: their gradients are scattered in one launch
+        base = self.flat.data_ptr()
+        self._mix_params = [b.mix_factor for b in self._blenders
+                            if b.merge_strategy != "fixed" and b.mix_factor.requires_grad and id(b.mix_factor) in self._gview]
+        self._mix_slots = torch.tensor([self._blender_slot[id(b)] for b in self._blenders
+                                        if b.merge_strategy != "fixed" and b.mix_factor.requires_grad
+                                        and id(b.mix_factor) in self._gview], dtype=torch.long, device=dev)
+        self._mix_idx = torch.tensor([(self._gview[id(p)].data_ptr() - base) // 4 for p in self._mix_params],
+                                     dtype=torch.long, device=dev)
         self._pack_tables = None
         self._pack_dtypes = None
         self._saved = None
@@ -740,30 +754,26 @@ class TrainPlan:
         self._pack_dtypes = (fdt, gdt)
 
     # ---- small kernels ----
-    def _alpha(self, blender) -> torch.Tensor:
-        """AlphaBlender.get_alpha per frame (util.py:342-356) -> [frames] fp32, and the mask of frames whose alpha follows
-        the mix factor (not an image-only frame)."""
-        key = id(blender)
-        hit = self._alphas.get(key)
-        if hit is not None:
-            return hit
+    def _make_alphas(self) -> None:
+        """AlphaBlender.get_alpha per frame (util.py:342-356) for ALL blenders of the network at once -> a [n_blenders,
+        frames] table (row = blender), and `live` = d alpha / d mix_factor per frame (0 on image-only frames and for the
+        "fixed" strategy).  A handful of launches per step instead of ~7 per blender."""
+        bl = self._blenders
         frames = self.N
         ioi = self.ioi.reshape(-1).bool()
-        if blender.merge_strategy == "fixed":
-            a = blender.mix_factor.detach().float().reshape(1).expand(frames).contiguous()
-            live = torch.zeros(frames, dtype=_f32, device=self.device)
-        else:
-            s = torch.sigmoid(blender.mix_factor.detach().float()).reshape(1)
-            a = s.expand(frames)
-            live = torch.ones(frames, dtype=_f32, device=self.device)
-            if blender.merge_strategy == "learned_with_images":
-                a = torch.where(ioi, torch.ones_like(a), a)
-                live = (~ioi).float()
-            a = a.contiguous()
-            live = live * (s * (1.0 - s))          # d alpha / d mix_factor on the live frames
-        slot = len(self._alphas)
-        self._alphas[key] = (a, live, slot, blender)
-        return self._alphas[key]
+        mix = torch.cat([b.mix_factor.detach().float().reshape(1) for b in bl])            # [n_bl]
+        fixed = self._blender_fixed
+        s = torch.sigmoid(mix)
+        a = torch.where(fixed, mix, s)[:, None].expand(len(bl), frames)
+        with_images = self._blender_with_images[:, None] & ioi[None, :]
+        a = torch.where(with_images, torch.ones_like(a), a).contiguous()
+        live = (s * (1.0 - s))[:, None].expand(len(bl), frames)
+        live = torch.where(with_images | fixed[:, None], torch.zeros_like(live), live).contiguous()
+        self._alpha_tab, self._live_tab = a, live
+
+    def _alpha(self, blender):
+        slot = self._blender_slot[id(blender)]
+        return self._alpha_tab[slot], self._live_tab[slot], slot, blender
 
     def blend_fwd(self, blender, xs, xt, rows):
         a = self._alpha(blender)[0]
@@ -811,7 +821,7 @@ class TrainPlan:
         if not torch.cuda.is_current_stream_capturing():
             self._decide_checkpoint(N * H * W)
         self.ioi = image_only_indicator.to(x.device)
-        self._alphas: Dict[int, tuple] = {}
+        self._make_alphas()
         if self._pack_tables is None or self._pack_dtypes != (A._dt(A.FWD_DTYPE), A._dt(A.GRAD_DTYPE)) or not A.PACK._d:
             self.repack()
         self._reached = set()
@@ -994,10 +1004,12 @@ class TrainPlan:
             for dvs, dvt in drow:
                 dys += [dvs, dvt]
         g1.backward(self, dys)
-        # the blenders' mix factors: d mix = sum over live frames of d alpha * s (1 - s)
-        for key, (a, live, slot, blender) in self._alphas.items():
-            if blender.merge_strategy != "fixed" and blender.mix_factor.requires_grad:
-                self.sink(blender.mix_factor, (self._dalpha[slot] * live).sum().reshape(1))
+        # the blenders' mix factors: d mix = sum over live frames of d alpha * s (1 - s) — all of them in three launches
+        if self._mix_params:
+            d_mix = (self._dalpha * self._live_tab).sum(1)[self._mix_slots]
+            self.flat.index_put_((self._mix_idx,), d_mix, accumulate=self.accumulate)
+            for p in self._mix_params:
+                self.touched(p)
         self._groups = None
 
 

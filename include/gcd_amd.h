@@ -372,9 +372,10 @@ int gcd_cast_f32_bf16(const float* x, int64_t ldx, void* y16, int64_t ldy, int64
 int gcd_cast_f16_bf16(const void* x16, int64_t ldx, void* y16, int64_t ldy, int64_t M, int C, void* stream);
 /* y16 = fp16 (or bfloat16 when to_bf16) of x AND sums[b][c] += sum of x over rows b*rows_per_block .. (sums zeroed by the
  * caller, [M / rows_per_block, C]): the incoming gradient of a Linear / convolution rounded for its GEMMs and summed
- * for its bias / per-frame-vector gradient in ONE pass over it.                                                      */
+ * for its bias / per-frame-vector gradient in ONE pass over it.  total_zeroed (ABI v7, optional): [C], receives the sums
+ * over ALL rows as well — the bias gradient of a node that also has a per-frame vector, with no second reduction.       */
 int gcd_cast_colsum_f32(const float* x, int64_t ldx, void* y16, int64_t ldy, int64_t M, int C, int64_t rows_per_block,
-                        float* sums_zeroed, int to_bf16, void* stream);
+                        float* sums_zeroed, int to_bf16, float* total_zeroed, void* stream);
 int gcd_cast_scale_f32_f16(const float* x, int64_t ldx, void* y16, int64_t ldy, int64_t M, int C,
                            float scale, void* stream);
 /* torch.optim.Adam step (no amsgrad; weight_decay added to the gradient), in place; grad_scale is

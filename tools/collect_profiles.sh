@@ -40,6 +40,9 @@ python tools/train_step_bench.py --steps 3 --clips 8 --checkpoint on > $OUT/trai
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/trace_train -o t -- python $ROOT/tools/train_step_bench.py --steps 9 \
     > /dev/null 2>&1)
 python tools/rocpd_stats.py $(find $OUT/trace_train -name "*_results.db" | head -1) --steps 10 > $OUT/train_kernel_stats.txt
+# launches per step without model construction: difference of a 10-step and a 5-step trace (tools/train_profile.sh), both engines
+for e in planned autograd; do bash tools/train_profile.sh $TAG/tp_$e $e > /dev/null 2>&1; cp $OUT/tp_$e/launches_per_step_$e.txt $OUT/; done
+cat $OUT/launches_per_step_*.txt
 # keep the summaries only: gpurun merges at most 64 MiB back
 rm -rf $OUT/trace $OUT/trace_train $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_TCC_HIT_sum $OUT/pmc_sq $OUT/pmc_sq2
 du -sh $ROOT/gpurun_out

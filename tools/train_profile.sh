@@ -11,7 +11,20 @@ python tools/train_step_bench.py --steps 5 > $O/train_${ENGINE}.json 2> $O/train
 cat $O/train_${ENGINE}.json
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python $ROOT/tools/train_step_bench.py --steps 9 > /dev/null 2>&1)
 python tools/rocpd_stats.py $(find $O/trace -name "*_results.db" | head -1) --steps 10 > $O/train_kernel_stats_${ENGINE}.txt
-rm -rf $O/trace
+# a second trace with 5 steps: (dispatches of 10 steps - dispatches of 5 steps) / 5 = launches per step, model construction excluded
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $O/trace5 -o t -- python $ROOT/tools/train_step_bench.py --steps 4 > /dev/null 2>&1)
+python tools/rocpd_stats.py $(find $O/trace5 -name "*_results.db" | head -1) --steps 5 > $O/train_kernel_stats_${ENGINE}_5steps.txt
+python - <<PY | tee $O/launches_per_step_${ENGINE}.txt
+import re
+def tot(f):
+    m = re.search(r"total GPU kernel time ([\d.]+) ms over (\d+) dispatches", open(f).read())
+    return float(m.group(1)), int(m.group(2))
+t10, n10 = tot("$O/train_kernel_stats_${ENGINE}.txt")
+t5, n5 = tot("$O/train_kernel_stats_${ENGINE}_5steps.txt")
+print(f"${ENGINE} engine: {(n10 - n5) / 5:.0f} launches per step, {(t10 - t5) / 5:.1f} ms of kernel time per step "
+      f"(10-step trace {n10} dispatches / {t10:.0f} ms, 5-step trace {n5} / {t5:.0f} ms; the rest is model construction)")
+PY
+rm -rf $O/trace $O/trace5
 python - <<PY
 import re
 rows = []
