@@ -84,19 +84,41 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const gcd_pack_entry*
     lds[(tap * PT + nl) * PPAD + cl] = to16(v, bf16 != 0);
   }
   __syncthreads();
+  // two 16-bit elements (4 bytes) per store where the pair is inside the tile and its address is 4-byte aligned (every
+  // full tile of the network's shapes); single elements at ragged edges / odd strides
   if (e.dst_f) {
     unsigned short* d = (unsigned short*)e.dst_f;
-    for (int i = t; i < taps * PT * PT; i += 256) {
-      const int cl = i & (PT - 1), nl = (i >> 5) & (PT - 1), tap = i >> 10;
-      if (nl < nw && cl < cw) d[(int64_t)(n0 + nl) * e.f_ns + (int64_t)tap * e.f_ts + c0 + cl] = lds[(tap * PT + nl) * PPAD + cl];
+    const bool pair_ok = ((e.f_ns | e.f_ts | c0) & 1) == 0 && (((uintptr_t)d) & 3) == 0 && (cw & 1) == 0;
+    for (int i = t; i < taps * PT * (PT / 2); i += 256) {
+      const int cl = (i & (PT / 2 - 1)) * 2, nl = (i >> 4) & (PT - 1), tap = i >> 9;
+      if (nl < nw && cl < cw) {
+        unsigned short* q = d + (int64_t)(n0 + nl) * e.f_ns + (int64_t)tap * e.f_ts + c0 + cl;
+        const unsigned short v0 = lds[(tap * PT + nl) * PPAD + cl], v1 = lds[(tap * PT + nl) * PPAD + cl + 1];
+        if (pair_ok) {
+          *(unsigned*)q = (unsigned)v0 | ((unsigned)v1 << 16);
+        } else {
+          q[0] = v0;
+          if (cl + 1 < cw) q[1] = v1;
+        }
+      }
     }
   }
   if (e.dst_t) {
     unsigned short* d = (unsigned short*)e.dst_t;
-    for (int i = t; i < taps * PT * PT; i += 256) {
-      const int nl = i & (PT - 1), cl = (i >> 5) & (PT - 1), tap = i >> 10;
+    const bool pair_ok = ((e.t_cs | e.t_ts | n0) & 1) == 0 && (((uintptr_t)d) & 3) == 0 && (nw & 1) == 0;
+    for (int i = t; i < taps * PT * (PT / 2); i += 256) {
+      const int nl = (i & (PT / 2 - 1)) * 2, cl = (i >> 4) & (PT - 1), tap = i >> 9;
       const int tx = e.mirror ? taps - 1 - tap : tap;
-      if (nl < nw && cl < cw) d[(int64_t)(c0 + cl) * e.t_cs + (int64_t)tx * e.t_ts + n0 + nl] = lds[(tap * PT + nl) * PPAD + cl];
+      if (nl < nw && cl < cw) {
+        unsigned short* q = d + (int64_t)(c0 + cl) * e.t_cs + (int64_t)tx * e.t_ts + n0 + nl;
+        const unsigned short v0 = lds[(tap * PT + nl) * PPAD + cl], v1 = lds[(tap * PT + nl + 1) * PPAD + cl];
+        if (pair_ok) {
+          *(unsigned*)q = (unsigned)v0 | ((unsigned)v1 << 16);
+        } else {
+          q[0] = v0;
+          if (nl + 1 < nw) q[1] = v1;
+        }
+      }
     }
   }
 }
