@@ -142,6 +142,7 @@ TRAIN_SIGNATURES = {
     "gcd_wgrad_tr_scratch_floats": (_i64, [_i64, _i, _i]),
     "gcd_wgrad_tr_f16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _i64, _vp, _i64, _vp]),
     "gcd_wgrad_tr_f16_ex": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp]),
+    "gcd_wgrad_conv_tr_f16": (_i, [_vp, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _i64, _vp]),
     "gcd_train_pack_weights": (_i, [_vp, _i, _i, _i, _vp]),
     "gcd_blend_fwd_f32": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i64, _vp, _i64, _vp]),
     "gcd_blend_bwd_f32": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i64, _vp, _i64, _i, _vp, _i64, _vp, _vp]),

@@ -186,6 +186,27 @@ def _wgrad(dy16: torch.Tensor, x16: torch.Tensor, dest: Optional[torch.Tensor] =
         return dw
     _gemm(_t16_padded(dy16), _t16_padded(x16), dw, M=N)       # split-K over the tokens
     return dw
+# A/B switch: the planned engine's convolution weight gradients gather X per tap inside the kernel (no im2col tensor)
+WGRAD_IMPLICIT = os.environ.get("GCD_TRAIN_WGRAD_IMPLICIT", "1") != "0"
+
+
+def _wgrad_conv(dy16: torch.Tensor, x16: torch.Tensor, dest: torch.Tensor, conv: int, n_real: int, c_real: int,
+                Ho: int = 0, Wo: int = 0, T: int = 0, HW: int = 0) -> torch.Tensor:
+    """Weight gradient of a stride-1 3x3 convolution (conv = 1) or the (3,1,1) temporal convolution (conv = 2) straight into
+    `dest` (the parameter's [Cout, Cin, taps...] slot): x16 [M, Cp] is the convolution's input operand, dy16 [M, N]."""
+    M, N = dy16.shape
+    Cp = x16.shape[1]
+    taps = 9 if conv == 1 else 3
+    lib = _lib.load_train()
+    scratch = torch.empty(int(lib.gcd_wgrad_tr_scratch_floats(M, N, taps * Cp)), dtype=_f32, device=dy16.device)
+    _lib.check_train(lib.gcd_wgrad_conv_tr_f16(
+        dy16.data_ptr(), dy16.stride(0), x16.data_ptr(), x16.stride(0), M, N, Cp, conv, Ho, Wo, T, HW,
+        int(dy16.dtype == _bf16), dest.data_ptr(), n_real, c_real,
+        int(bool(_GRAD_SINK is not None and _GRAD_SINK.accumulate)), scratch.data_ptr(), scratch.numel(), _stream()),
+        "gcd_wgrad_conv_tr_f16")
+    return dest
+
+
 _WS = {}
 
 
@@ -512,7 +533,11 @@ def _contract_bwd(kind, dy, a16, params, geo, need_da, need_dw, dy16=None, db_pr
                 dxo = dxo.reshape(frames, Hi, 2, Wi, 2, cin_p).sum(dim=(2, 4)).reshape(Min, cin_p)
             da = dxo[:, :Cin] if cin_p != Cin else dxo
         col = None
-        if need_dw[0] or (need_da and da is None):
+        # planned engine, stride-1 same-size convolutions: the weight gradient gathers its X operand per tap inside the
+        # kernel (gcd_wgrad_conv_tr_f16) — no im2col tensor
+        dst = _sink_dest(weight) if need_dw[0] else None
+        implicit = dst is not None and geo["stride"] == 1 and not geo["upsample"] and WGRAD_IMPLICIT
+        if (need_dw[0] and not implicit) or (need_da and da is None):
             xg = _as_dtype(a16, dt)
             col = torch.empty(Mout, 9 * cin_p, dtype=dt, device=dev)
             check(lib.gcd_im2col3x3_f16(xg.data_ptr(), _ld(xg), col.data_ptr(), frames, cin_p, Hi, Wi, Ho, Wo,
@@ -528,8 +553,9 @@ def _contract_bwd(kind, dy, a16, params, geo, need_da, need_dw, dy16=None, db_pr
                                         geo["stride"], geo["upsample"], 0, _stream()), "gcd_col2im3x3_f32")
             da = dxp[:, :Cin] if cin_p != Cin else dxp
         if need_dw[0]:
-            dst = _sink_dest(weight)
-            if dst is not None:           # straight into the parameter's [Cout, Cin, 3, 3] slot, cropped
+            if implicit:
+                dw = _wgrad_conv(dy16, _as_dtype(a16, dt), dst[0], 1, Cout, Cin, Ho=Ho, Wo=Wo)
+            elif dst is not None:           # straight into the parameter's [Cout, Cin, 3, 3] slot, cropped
                 dw = _wgrad(dy16, col, dest=dst[0], taps=9, n_real=Cout, c_real=Cin)
             else:
                 dwp = _wgrad(dy16, col)       # dW = dY^T col [cout_p, 9 * cin_p], contraction over the tokens
@@ -546,12 +572,14 @@ def _contract_bwd(kind, dy, a16, params, geo, need_da, need_dw, dy16=None, db_pr
             wd = PACK.get(weight, f"t3d_{dt}", _pack_t3_dgrad(dt))          # [Cin, 3*Cout]
             da = torch.empty(M, Cc, dtype=_f32, device=dev)
             _gemm(dy16, wd, da, M=M, mode=GEMM_TEMPORAL3, conv=dict(Cin=Cout, T=geo["T"], HW=geo["HW"]))
-        if need_dw[0]:
+        dst = _sink_dest(weight) if need_dw[0] else None
+        if need_dw[0] and dst is not None and WGRAD_IMPLICIT:
+            dw = _wgrad_conv(dy16, _as_dtype(a16, dt), dst[0], 2, Cout, Cc, T=geo["T"], HW=geo["HW"])
+        elif need_dw[0]:
             xg = _as_dtype(a16, dt)
             col = torch.empty(M, 3 * Cc, dtype=dt, device=dev)
             check(lib.gcd_im2col_t3_f16(xg.data_ptr(), _ld(xg), col.data_ptr(), M, Cc, geo["T"], geo["HW"],
                                         _stream()), "gcd_im2col_t3_f16")
-            dst = _sink_dest(weight)
             if dst is not None:
                 dw = _wgrad(dy16, col, dest=dst[0], taps=3, n_real=Cout, c_real=Cc)
             else:

@@ -105,3 +105,43 @@ extern "C" int gcd_wgrad_tr_f16_ex(const void* dy16, int64_t lddy, const void* x
   }
   return 0;
 }
+
+// The weight gradient of a stride-1 3 x 3 convolution (conv = 1) or of the (3,1,1) temporal convolution (conv = 2) with the
+// X operand gathered IMPLICITLY per tap (train_wgrad_kernel.h, CONV): x16 is the convolution's INPUT activation [M, Cp]
+// (token-major, the operand the forward pass left), dy16 [M, N] its output gradient; K = taps * Cp.  The result lands in the
+// parameter's layout [N_real][C_real][taps] as gcd_wgrad_tr_f16_ex's.  No im2col tensor.
+extern "C" int gcd_wgrad_conv_tr_f16(const void* dy16, int64_t lddy, const void* x16, int64_t ldx, int64_t M, int N, int Cp,
+                                     int conv, int Ho, int Wo, int T, int HW, int bf16, float* dW, int N_real, int C_real,
+                                     int accumulate, float* scratch, int64_t scratch_floats, void* stream) {
+  CHECK_ARG(conv == 1 || conv == 2, "gcd_wgrad_conv_tr_f16: conv=%d (1: 3x3 stride 1, 2: (3,1,1))", conv);
+  const int taps = conv == 1 ? 9 : 3;
+  const int K = taps * Cp;
+  CHECK_ARG(dy16 && x16 && dW && scratch, "gcd_wgrad_conv_tr_f16: null pointer");
+  CHECK_ARG(M > 0 && N > 0 && Cp > 0 && N % 8 == 0 && Cp % 8 == 0 && lddy % 8 == 0 && lddy >= N && ldx % 8 == 0 && ldx >= Cp,
+            "gcd_wgrad_conv_tr_f16: M=%lld N=%d Cp=%d lddy=%lld ldx=%lld", (long long)M, N, Cp, (long long)lddy, (long long)ldx);
+  CHECK_ARG(N_real >= 1 && N_real <= N && C_real >= 1 && C_real <= Cp, "gcd_wgrad_conv_tr_f16: N_real=%d C_real=%d", N_real,
+            C_real);
+  if (conv == 1) CHECK_ARG(Ho > 0 && Wo > 0 && M % ((int64_t)Ho * Wo) == 0, "gcd_wgrad_conv_tr_f16: M=%lld is not frames x %d x %d",
+                           (long long)M, Ho, Wo);
+  else CHECK_ARG(T > 0 && HW > 0 && M % ((int64_t)T * HW) == 0, "gcd_wgrad_conv_tr_f16: M=%lld is not clips x %d x %d",
+                 (long long)M, T, HW);
+  CHECK_ARG((((uintptr_t)dy16 | (uintptr_t)x16 | (uintptr_t)dW | (uintptr_t)scratch) & 15) == 0,
+            "gcd_wgrad_conv_tr_f16: operands must be 16-byte aligned");
+  const int64_t need = gcd_wgrad_tr_scratch_floats(M, N, K);
+  CHECK_ARG(scratch_floats >= need, "gcd_wgrad_conv_tr_f16: scratch of %lld floats, need %lld", (long long)scratch_floats,
+            (long long)need);
+  const gcd_wgrad::Layout lay = {taps, N_real, C_real, accumulate};
+  const gcd_wgrad::ConvGeo geo = {conv, Cp, Ho, Wo, T, HW};
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e;
+  const bool big = wgrad_tm(M, N, K) == 64;
+#define GCD_WC(BF, TMV, CV) gcd_wgrad::launch<BF, TMV, CV>(dy16, lddy, x16, ldx, M, N, K, dW, C_real, lay, scratch, s, geo)
+  if (conv == 1) e = big ? (bf16 ? GCD_WC(true, 64, 1) : GCD_WC(false, 64, 1)) : (bf16 ? GCD_WC(true, 32, 1) : GCD_WC(false, 32, 1));
+  else e = big ? (bf16 ? GCD_WC(true, 64, 2) : GCD_WC(false, 64, 2)) : (bf16 ? GCD_WC(true, 32, 2) : GCD_WC(false, 32, 2));
+#undef GCD_WC
+  if (e != hipSuccess) {
+    set_error("gcd_wgrad_conv_tr_f16: launch failed: %s", hipGetErrorString(e));
+    return 1;
+  }
+  return 0;
+}

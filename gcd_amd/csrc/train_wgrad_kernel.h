@@ -56,10 +56,20 @@ __device__ __forceinline__ f16x8 frag_tr(const char* tile, int r0, int c0, int l
 // part[s][N][K].  128 x 128 output tile, 4 waves of 64 x 64 (16 accumulators of v_mfma_f32_16x16x32), TM tokens per
 // step (32 or 64: one barrier per 16 / 32 MFMAs of a wave), operands through registers into a double-buffered LDS tile.
 // The 16-bit payload travels as f16x8 bit patterns; BF16 only selects the MFMA.  Dynamic LDS: smem_bytes(TM).
-template <bool BF16, int TM>
+// CONV (round 5): the X operand of a convolution's weight gradient read IMPLICITLY — column k = tap * Cp + c of the
+// contraction is channel c of the input token that tap `tap` pairs with output token m (zero outside the image / clip) —
+// instead of from an im2col'd copy (43 008 x 2880 fp16 = 248 MB written and re-read per L0 convolution).
+//   1: Conv2d 3x3, stride 1, same size (rows are (frame, y, x); tap = 3 kh + kw pairs m with m + (kh - 1) Wo + (kw - 1))
+//   2: Conv3d (3,1,1) over the T frames of a clip (rows are (clip, t, hw); tap kt pairs m with m + (kt - 1) HW)
+struct ConvGeo {
+  int conv, Cp, Ho, Wo, T, HW;
+};
+
+template <bool BF16, int TM, int CONV = 0>
 __global__ __launch_bounds__(256) void wgrad_tr_kernel(const f16* __restrict__ dY, int64_t lddy,
                                                        const f16* __restrict__ X, int64_t ldx,
-                                                       float* __restrict__ part, int64_t M, int N, int K, int64_t mper) {
+                                                       float* __restrict__ part, int64_t M, int N, int K, int64_t mper,
+                                                       ConvGeo geo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE_BYTES = TM * PITCH, NP = TM / 16;     // NP: 16-row staging passes per operand
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -71,6 +81,31 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const f16* __restrict__ d
   const int nsteps = m_end > m_begin ? (int)((m_end - m_begin + TM - 1) / TM) : 0;
   const int srow = t >> 4, schunk = t & 15;      // staging: row t / 16 (+ 16 per pass), 16-byte chunk t % 16 of a tile row
   f16x8 ra[NP], rb[NP];
+  // CONV: this thread's 16-byte chunk of the K-tile belongs to ONE tap (Cp % 8 == 0): its row shift and channel offset are
+  // fixed; the image / clip position of each of its NP rows is a running counter advanced by TM per step (gload is called
+  // for steps 0, 1, 2, ... in order), so no division sits in the loop.
+  int c_tap = 0, c_ch = 0, p_a[NP], p_b[NP];
+  int64_t c_shift = 0;
+  if constexpr (CONV != 0) {
+    const int k = k0 + 8 * schunk;
+    c_tap = k / geo.Cp;
+    c_ch = k - c_tap * geo.Cp;
+    if (CONV == 1) c_shift = (int64_t)(c_tap / 3 - 1) * geo.Wo + (c_tap % 3 - 1);
+    else c_shift = (int64_t)(c_tap - 1) * geo.HW;
+#pragma unroll
+    for (int h = 0; h < NP; ++h) {
+      const int64_t m = m_begin + srow + 16 * h;
+      if (CONV == 1) {       // p_a = y, p_b = x of the output token
+        const int64_t r = m % ((int64_t)geo.Ho * geo.Wo);
+        p_a[h] = (int)(r / geo.Wo);
+        p_b[h] = (int)(r - (int64_t)p_a[h] * geo.Wo);
+      } else {               // p_a = frame within the clip, p_b = pixel
+        const int64_t f = m / geo.HW;
+        p_a[h] = (int)(f % geo.T);
+        p_b[h] = (int)(m - f * geo.HW);
+      }
+    }
+  }
   auto gload = [&](int step) {
 #pragma unroll
     for (int h = 0; h < NP; ++h) {
@@ -78,7 +113,29 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const f16* __restrict__ d
       const int n = n0 + 8 * schunk, k = k0 + 8 * schunk;
       const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
       ra[h] = (m < m_end && n < N) ? *(const f16x8*)(dY + m * lddy + n) : z;
-      rb[h] = (m < m_end && k < K) ? *(const f16x8*)(X + m * ldx + k) : z;
+      if constexpr (CONV == 0) {
+        rb[h] = (m < m_end && k < K) ? *(const f16x8*)(X + m * ldx + k) : z;
+      } else {
+        bool ok = m < m_end && k < K;
+        if (CONV == 1) {
+          const int yy = p_a[h] + c_tap / 3 - 1, xx = p_b[h] + c_tap % 3 - 1;
+          ok = ok && (unsigned)yy < (unsigned)geo.Ho && (unsigned)xx < (unsigned)geo.Wo;
+          p_b[h] += TM;                                   // this row's position at the next step
+          while (p_b[h] >= geo.Wo) {
+            p_b[h] -= geo.Wo;
+            if (++p_a[h] == geo.Ho) p_a[h] = 0;
+          }
+        } else {
+          const int tt = p_a[h] + c_tap - 1;
+          ok = ok && (unsigned)tt < (unsigned)geo.T;
+          p_b[h] += TM;
+          while (p_b[h] >= geo.HW) {
+            p_b[h] -= geo.HW;
+            if (++p_a[h] == geo.T) p_a[h] = 0;
+          }
+        }
+        rb[h] = ok ? *(const f16x8*)(X + (m + c_shift) * ldx + c_ch) : z;
+      }
     }
   };
   auto lstore = [&](int buf) {
@@ -192,13 +249,13 @@ inline int slices(int64_t M, int N, int K) {
 
 // Launch both passes on `s` with TM tokens per step (32 or 64; 64 needs the > 64 KB dynamic-LDS opt-in, done here once per
 // process and device by the caller's flag).  Returns the HIP error of the launches.
-template <bool BF16, int TM>
+template <bool BF16, int TM, int CONV = 0>
 inline hipError_t launch(const void* dy16, int64_t lddy, const void* x16, int64_t ldx, int64_t M, int N, int K,
-                         float* dW, int64_t lddw, Layout lay, float* scratch, hipStream_t s) {
+                         float* dW, int64_t lddw, Layout lay, float* scratch, hipStream_t s, ConvGeo geo = ConvGeo{0, 0, 0, 0, 0, 0}) {
   const int S = slices(M, N, K);
   const int64_t mper = ((M + S - 1) / S + TM - 1) / TM * TM;
   const dim3 grid((K + TK - 1) / TK, (N + TN - 1) / TN, S);
-  auto fn = wgrad_tr_kernel<BF16, TM>;
+  auto fn = wgrad_tr_kernel<BF16, TM, CONV>;
   if (smem_bytes(TM) > 64 * 1024) {
     // the > 64 KB dynamic-LDS opt-in: ONE driver call per process, device and instantiation (not one per weight
     // gradient; also keeps the launch path free of driver calls under stream capture after the first step)
@@ -213,7 +270,7 @@ inline hipError_t launch(const void* dy16, int64_t lddy, const void* x16, int64_
     }
   }
   hipLaunchKernelGGL(fn, grid, dim3(256), smem_bytes(TM), s, (const f16*)dy16, lddy, (const f16*)x16, ldx, scratch, M, N, K,
-                     mper);
+                     mper, geo);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (lay.taps > 1)

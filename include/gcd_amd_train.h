@@ -36,6 +36,15 @@ int gcd_wgrad_tr_f16_ex(const void* dy16, int64_t lddy, const void* x16, int64_t
                         float* dW, int64_t lddw, int taps, int N_real, int C_real, int accumulate, float* scratch,
                         int64_t scratch_floats, void* stream);
 
+/* The weight gradient of a convolution WITHOUT an im2col'd operand (round 5): conv = 1: Conv2d 3x3, stride 1, same size
+ * (openaimodel.py:270-318; rows of x16 / dy16 are (frame, y, x), M = frames * Ho * Wo); conv = 2: Conv3d (3,1,1) over the T
+ * frames of a clip (video_model.py:42-60; rows (clip, t, hw), M = clips * T * HW).  x16 [M, Cp] is the convolution's INPUT
+ * activation as the forward pass left it; column tap * Cp + c of the contraction is gathered per tap inside the kernel
+ * (zero outside the image / clip).  dW receives the parameter's layout [N_real][C_real][taps] (taps = 9 / 3), cropped. */
+int gcd_wgrad_conv_tr_f16(const void* dy16, int64_t lddy, const void* x16, int64_t ldx, int64_t M, int N, int Cp, int conv,
+                          int Ho, int Wo, int T, int HW, int bf16, float* dW, int N_real, int C_real, int accumulate,
+                          float* scratch, int64_t scratch_floats, void* stream);
+
 /* ---- multi-tensor weight pack (train_ops.hip) -------------------------------------------------------------------------
  * One launch turns fp32 parameters into the 16-bit operand forms of the forward and backward GEMMs.  Entry: the parameter
  * viewed as [N][C][taps] contiguous (Linear / 1x1 conv: taps = 1; Conv2d 3x3: 9; Conv3d (3,1,1): 3), written, rounded once

@@ -362,3 +362,53 @@ def test_planned_engine_gradient_accumulation(gpu):
                 worst = max(worst, rel_l2(p.grad, want))
     print(f"accumulated vs summed gradients: worst {worst:.1e}")
     assert worst < 1e-3
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_conv_weight_gradients_without_im2col(gpu, bf16):
+    """gcd_wgrad_conv_tr_f16: the weight gradient of a stride-1 3x3 convolution and of the (3,1,1) temporal convolution with
+    the X operand gathered per tap inside the kernel (no im2col tensor), written in the parameter's layout, cropped —
+    against torch.nn.grad.conv{2,3}d_weight in fp32 on the 16-bit-rounded operands; ragged token counts, padded channels,
+    more than one token slice, accumulate."""
+    import torch.nn.functional as F
+    from gcd_amd import _lib
+    dt = torch.bfloat16 if bf16 else torch.float16
+    lib = _lib.load_train()
+    g = torch.Generator().manual_seed(61)
+
+    def run(dy_tok, x_tok, N, Cp, conv, Nr, Cr, **geo):
+        M = dy_tok.shape[0]
+        taps = 9 if conv == 1 else 3
+        dst = torch.full((Nr, Cr, taps), 3.0, device=gpu)
+        scratch = torch.empty(int(lib.gcd_wgrad_tr_scratch_floats(M, N, taps * Cp)), device=gpu)
+        outs = []
+        for acc in (0, 1):
+            _lib.check_train(lib.gcd_wgrad_conv_tr_f16(
+                dy_tok.data_ptr(), dy_tok.stride(0), x_tok.data_ptr(), x_tok.stride(0), M, N, Cp, conv, geo.get("Ho", 0),
+                geo.get("Wo", 0), geo.get("T", 0), geo.get("HW", 0), int(bf16), dst.data_ptr(), Nr, Cr, acc, scratch.data_ptr(),
+                scratch.numel(), _stream()), "wgrad_conv")
+            torch.cuda.synchronize()
+            outs.append(dst.clone())
+        return outs
+    # ---- 3x3: frames x H x W tokens, Cin 8 real of Cp 64 (the UNet's first convolution), Cout 40 ----
+    for frames, H, W, Cin, Cp, Cout, N in [(3, 7, 9, 8, 64, 40, 40), (5, 16, 24, 72, 72, 64, 64), (2, 33, 48, 64, 64, 4, 32)]:
+        x = (torch.randn(frames, Cin, H, W, generator=g)).to(dt).float()
+        dy = (torch.randn(frames, Cout, H, W, generator=g) * 0.5).to(dt).float()
+        ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, 3, 3), dy, padding=1).reshape(Cout, Cin, 9)
+        xt = torch.zeros(frames * H * W, Cp)
+        xt[:, :Cin] = x.permute(0, 2, 3, 1).reshape(-1, Cin)
+        dyt = torch.zeros(frames * H * W, N)
+        dyt[:, :Cout] = dy.permute(0, 2, 3, 1).reshape(-1, Cout)
+        o0, o1 = run(dyt.to(dt).to(gpu), xt.to(dt).to(gpu), N, Cp, 1, Cout, Cin, Ho=H, Wo=W)
+        assert rel_l2(o0, ref) < 2e-4, (frames, H, W, rel_l2(o0, ref))
+        assert rel_l2(o1, 2 * ref) < 2e-4
+    # ---- (3,1,1): clips x T x HW tokens ----
+    for clips, T, HW, Cc, Cout in [(2, 5, 12, 64, 64), (3, 14, 35, 72, 40)]:
+        x = torch.randn(clips, Cc, T, HW, 1, generator=g).to(dt).float()
+        dy = (torch.randn(clips, Cout, T, HW, 1, generator=g) * 0.5).to(dt).float()
+        ref = torch.nn.grad.conv3d_weight(x, (Cout, Cc, 3, 1, 1), dy, padding=(1, 0, 0)).reshape(Cout, Cc, 3)
+        xt = x.permute(0, 2, 3, 4, 1).reshape(-1, Cc)
+        dyt = dy.permute(0, 2, 3, 4, 1).reshape(-1, Cout)
+        o0, o1 = run(dyt.to(dt).to(gpu).contiguous(), xt.to(dt).to(gpu).contiguous(), Cout, Cc, 2, Cout, Cc, T=T, HW=HW)
+        assert rel_l2(o0, ref) < 2e-4, (clips, T, HW, rel_l2(o0, ref))
+        assert rel_l2(o1, 2 * ref) < 2e-4
