@@ -140,11 +140,11 @@ class _SmallGroup:
         self.items: List[dict] = []
         self._tabs: Dict[str, tuple] = {}
 
-    def add(self, x, lin: nn.Linear, y, silu_in=False, accumulate=False, dx=None, dx_silu=False, weight=None, bias=None):
-        """x [M, K] fp32 (row-major view), y [M, N] fp32 output.  dx: where the input gradient accumulates (zeroed by the
-        caller), or None when x needs no gradient."""
-        w = lin.weight if weight is None else weight
-        b = (lin.bias if lin is not None else None) if bias is None else bias
+    def add(self, x, lin: nn.Linear, y, silu_in=False, accumulate=False, dx=None, dx_silu=False):
+        """y = act(x) lin.weight^T + lin.bias: x [M, K] fp32 (row-major view), y [M, N] fp32 output (accumulate: y += ...;
+        never two problems of one launch onto the same y — they run concurrently).  dx: where the input gradient
+        accumulates (zeroed by the caller; several problems may share it), or None when x needs no gradient."""
+        w, b = lin.weight, lin.bias
         assert x.dtype == _f32 and y.dtype == _f32 and x.stride(1) == 1 and y.stride(1) == 1
         assert x.shape[1] % 4 == 0 and w.is_contiguous()
         self.items.append(dict(x=x, w=w, b=b, y=y, silu=silu_in, acc=accumulate, dx=dx, dx_silu=dx_silu))
@@ -491,11 +491,10 @@ class TrainPlan:
                                      dtype=torch.long, device=dev)
         self._pack_tables = None
         self._pack_dtypes = None
-        self._saved = None
 
     # ---- activation checkpointing: a memory decision, made against 288 GB ----
     # bytes of unit contexts kept per (L0 token x model channel) when nothing is recomputed: measured on the full-width
-    # network, 2 clips 54.2 GB vs 32.8 GB peak and 8 clips 132 GB vs 47 GB (profiles/r05_train_checkpoint.txt)
+    # network, 2 clips 54.3 GB vs 32.9 GB peak and 8 clips 132 GB vs 47 GB (profiles/r05_train_step_fp16*.json)
     CTX_BYTES_PER_TOKEN_CHANNEL = 1600
 
     def set_checkpoint(self, use_checkpoint: Optional[bool]) -> None:
@@ -585,12 +584,6 @@ class TrainPlan:
             else:
                 dst.copy_(g)
         self.touched(p)
-
-    def publish_grads(self) -> None:
-        """p.grad = the parameter's view of the flat buffer, for every parameter this step reached."""
-        for p in self.unet.parameters():
-            if id(p) in self._reached:
-                p.grad = self._gview[id(p)]
 
     # ---- structure ----
     def _build_units(self):

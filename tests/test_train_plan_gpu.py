@@ -370,7 +370,6 @@ def test_conv_weight_gradients_without_im2col(gpu, bf16):
     the X operand gathered per tap inside the kernel (no im2col tensor), written in the parameter's layout, cropped —
     against torch.nn.grad.conv{2,3}d_weight in fp32 on the 16-bit-rounded operands; ragged token counts, padded channels,
     more than one token slice, accumulate."""
-    import torch.nn.functional as F
     from gcd_amd import _lib
     dt = torch.bfloat16 if bf16 else torch.float16
     lib = _lib.load_train()
