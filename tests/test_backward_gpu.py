@@ -230,7 +230,7 @@ def test_temporal_attention_backward(gpu, clips, T, HW, heads):
 @pytest.mark.parametrize("M,N,K", [(4096, 320, 1280), (1000, 208, 336), (2688, 1280, 640), (100, 8, 24),
                                    # M >= 32768 and N K >= 400 000: the library picks the 64-TOKEN form (69 632 B of dynamic
                                    # LDS behind the opt-in) — what cfg4's large weight gradients run; ragged token count
-                                   (43000, 1280, 640)])
+                                   (32776, 1024, 400)])
 def test_weight_gradient_transposing_read_kernel(gpu, M, N, K, dtype):
     """gcd_wgrad_tr_f16 (libgcd_amd_train.so): dW = dY^T X with both operands row-major, transposed on the LDS read
     (ds_read_b64_tr_b16) — against fp32 torch and against the round-3 path (transposed copies + split-K gcd_gemm_f16),
@@ -440,9 +440,17 @@ def test_video_resblock_and_transformer_gradients_vs_oracle(gpu):
     assert dead >= 8, "the one-key cross-attention's q / k / norm2 must receive exactly zero gradient"
 
 
+# The autograd engine of rounds 2-4 stays in the tree and is compared with the planned engine on the same kernels in
+# tests/test_train_plan_gpu.py; its own runs through the end-to-end goldens below are duplicates of what rounds 2-4
+# recorded (and cost 70 s of GPU time): they run with GCD_TEST_FULL=1 (profiles/r05_gpu_tests_tail.log: all of them green).
+_FULL = __import__("os").environ.get("GCD_TEST_FULL", "0") == "1"
+
+
 @pytest.fixture
 def train_engine(request):
     """Run a test on one of the two engines of the fine-tune step (training.TRAIN_ENGINE), restoring the default."""
+    if request.param == "autograd" and not _FULL:
+        pytest.skip("autograd-engine duplicate of an end-to-end golden run: GCD_TEST_FULL=1")
     from gcd_amd import training as TR
     old = TR.TRAIN_ENGINE
     TR.set_train_engine(request.param)
