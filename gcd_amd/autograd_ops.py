@@ -901,6 +901,8 @@ class SpatialAttention(torch.autograd.Function):
         ops.attn_spatial(qkv16, vt, S_pad, out16, frames, S, heads, q_prescaled=False)
         ctx.save_for_backward(qkv16, out16)
         ctx.dims = (frames, S, heads)
+        if getattr(ctx, "want16", False):      # planned engine: the fp16 result IS the next Linear's operand (no fp32 image)
+            return out16
         _LAST_F16[0] = out16
         return out16.float()
 
@@ -950,6 +952,8 @@ class TemporalAttention(torch.autograd.Function):
         ops.attn_temporal(qkv16, out16, clips, T, HW, heads)
         ctx.save_for_backward(qkv16)
         ctx.dims = (clips, T, HW, heads)
+        if getattr(ctx, "want16", False):
+            return out16
         _LAST_F16[0] = out16
         return out16.float()
 

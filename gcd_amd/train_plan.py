@@ -74,6 +74,18 @@ def _fused_fwd(kind, x, params, geo=None, norm=None, residual=None, rowvec=None)
     return y, ctx
 
 
+def _fused_fwd_from16(kind, x16, params, residual=None, rowvec=None):
+    """A Linear whose input already exists as the 16-bit operand (an attention core's fp16 output): no fp32 image of it, no
+    cast back (autograd_ops' fp16 pass-through, which the autograd engine measured slower because it holds the tensors)."""
+    x16._gcd_f16 = (x16, x16._version)
+    old, A._F16_PASSTHROUGH = A._F16_PASSTHROUGH, True
+    try:
+        return _fused_fwd(kind, x16, params, residual=residual, rowvec=rowvec)
+    finally:
+        A._F16_PASSTHROUGH = old
+        del x16._gcd_f16          # (the tag refers to the tensor itself: no reference cycle left behind)
+
+
 def _fused_bwd(plan: "TrainPlan", ctx: _Ctx, dy: torch.Tensor, need_x: bool = True, need_vec: bool = True, dx_add=None):
     """-> (dx | None, d_vec | None).  Parameter gradients go to `plan.sink`.  dx_add: another gradient of the same input
     (the residual branch's), added to dx — inside the LayerNorm / GroupNorm backward kernel when the node has one."""
@@ -335,9 +347,11 @@ class _AttnUnit:
             # spatial BasicTransformerBlock (attention.py:551-572)
             qkv, cq = _fused_fwd("qkv", h, (sb.attn1.to_q.weight, sb.attn1.to_k.weight, sb.attn1.to_v.weight), norm=_ln(sb.norm1))
             sa = _Ctx()
+            sa.want16 = True
             o = A.SpatialAttention.forward(sa, qkv, N, HW, heads)
             del qkv
-            h1, co = _fused_fwd("lin", o, (sb.attn1.to_out[0].weight, sb.attn1.to_out[0].bias), residual=h, rowvec=(ca_s, HW))
+            h1, co = _fused_fwd_from16("lin", o, (sb.attn1.to_out[0].weight, sb.attn1.to_out[0].bias), residual=h,
+                                       rowvec=(ca_s, HW))
             del o, h
             cl: List = [cq, sa, co]
             h2 = self._ff(sb.ff, h1, sb.norm3, cl)
@@ -347,10 +361,11 @@ class _AttnUnit:
             xm = self._ff(tb.ff_in, xm, tb.norm_in, cl)
             qkv, cq = _fused_fwd("qkv", xm, (tb.attn1.to_q.weight, tb.attn1.to_k.weight, tb.attn1.to_v.weight), norm=_ln(tb.norm1))
             ta = _Ctx()
+            ta.want16 = True
             o = A.TemporalAttention.forward(ta, qkv, clips, T, HW, heads)
             del qkv
-            xm2, co = _fused_fwd("lin", o, (tb.attn1.to_out[0].weight, tb.attn1.to_out[0].bias), residual=xm,
-                                 rowvec=(ca_t, T * HW))
+            xm2, co = _fused_fwd_from16("lin", o, (tb.attn1.to_out[0].weight, tb.attn1.to_out[0].bias), residual=xm,
+                                        rowvec=(ca_t, T * HW))
             del o, xm
             cl += [cq, ta, co]
             xm3 = self._ff(tb.ff, xm2, tb.norm3, cl)
