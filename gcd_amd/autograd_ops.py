@@ -444,6 +444,12 @@ def _contract_fwd(kind, a16, params, geo, bias_vec_res):
         M = a16.shape[0]
         dt = a16.dtype
         w16 = PACK.get_multi(params, f"qkv_{dt}", lambda ws: torch.cat([w.to(dt) for w in ws], 0).contiguous())
+        if geo is not None and geo.get("out16") and dt == _f16 and not bias_vec_res:
+            # planned engine: q | k | v leave the GEMM as the fp16 tensor the attention core reads (what the inference
+            # engine does) — no fp32 result, no cast pass
+            y = torch.empty(M, w16.shape[0], dtype=_f16, device=dev)
+            _gemm(a16, w16, y, M=M, out_kind=OUT_F16)
+            return y
         y = torch.empty(M, w16.shape[0], dtype=_f32, device=dev)
         _gemm(a16, w16, y, M=M, **bias_vec_res)
         return y
@@ -893,7 +899,7 @@ class SpatialAttention(torch.autograd.Function):
         M, C3 = qkv.shape
         Cc = C3 // 3
         assert M == frames * S and Cc == heads * 64
-        qkv16 = _cast16(qkv.contiguous())
+        qkv16 = qkv if qkv.dtype == _f16 and qkv.is_contiguous() else _cast16(qkv.contiguous())
         S_pad = (S + 63) // 64 * 64
         vt = torch.empty(frames * heads * 64 * S_pad, dtype=_f16, device=qkv.device)
         ops.attn_transpose_v(qkv16, frames, S, heads, vt, S_pad)
@@ -947,7 +953,7 @@ class TemporalAttention(torch.autograd.Function):
         ops._need_gpu(qkv)
         M, C3 = qkv.shape
         Cc = C3 // 3
-        qkv16 = _cast16(qkv.contiguous())
+        qkv16 = qkv if qkv.dtype == _f16 and qkv.is_contiguous() else _cast16(qkv.contiguous())
         out16 = torch.empty(M, Cc, dtype=_f16, device=qkv.device)
         ops.attn_temporal(qkv16, out16, clips, T, HW, heads)
         ctx.save_for_backward(qkv16)

@@ -130,6 +130,9 @@ def _ln(m):
     return ("ln", m, 1e-5)
 
 
+_QKV16 = dict(out16=True)      # q | k | v straight out of the GEMM in fp16 (autograd_ops._contract_fwd)
+
+
 def zeros_or_new(plan, m, n):
     z = plan.zeros(m, n)
     return z if z is not None else torch.zeros(m, n, dtype=_f32, device=plan.device)
@@ -345,7 +348,8 @@ class _AttnUnit:
         for d, (sb, tb) in enumerate(zip(tr.transformer_blocks, tr.time_stack)):
             ca_s, ca_t, pos = vecs[d]
             # spatial BasicTransformerBlock (attention.py:551-572)
-            qkv, cq = _fused_fwd("qkv", h, (sb.attn1.to_q.weight, sb.attn1.to_k.weight, sb.attn1.to_v.weight), norm=_ln(sb.norm1))
+            qkv, cq = _fused_fwd("qkv", h, (sb.attn1.to_q.weight, sb.attn1.to_k.weight, sb.attn1.to_v.weight), norm=_ln(sb.norm1),
+                                 geo=_QKV16)
             sa = _Ctx()
             sa.want16 = True
             o = A.SpatialAttention.forward(sa, qkv, N, HW, heads)
@@ -359,7 +363,8 @@ class _AttnUnit:
             # temporal VideoTransformerBlock (video_attention.py:109-140) on x + frame position embedding
             xm = plan.add_rowvec(h2, pos, HW)
             xm = self._ff(tb.ff_in, xm, tb.norm_in, cl)
-            qkv, cq = _fused_fwd("qkv", xm, (tb.attn1.to_q.weight, tb.attn1.to_k.weight, tb.attn1.to_v.weight), norm=_ln(tb.norm1))
+            qkv, cq = _fused_fwd("qkv", xm, (tb.attn1.to_q.weight, tb.attn1.to_k.weight, tb.attn1.to_v.weight), norm=_ln(tb.norm1),
+                                 geo=_QKV16)
             ta = _Ctx()
             ta.want16 = True
             o = A.TemporalAttention.forward(ta, qkv, clips, T, HW, heads)
