@@ -344,3 +344,32 @@ def test_pack_cache_registry_semantics():
     assert pc._reg[ptr]() is None
     pc.clear()
     assert not pc._d
+
+
+def test_train_engine_switch_and_planned_engine_refuse_loudly():
+    """Host logic of round 5's engine switch: unknown names raise (an environment typo must not silently pick an engine);
+    the planned engine refuses a network that is not on a GPU — there is no CPU path — and GradBucketer registers /
+    unregisters its listener for the planned engine's in-place gradients."""
+    import torch
+    from gcd_amd import _lib, autograd_ops as A, train_plan as TP, training as TR
+    from gcd_amd.video_model import VideoUNet
+    from oracle import svd_unet_ref as O
+    old = TR.TRAIN_ENGINE
+    try:
+        TR.set_train_engine("autograd")
+        assert TR.TRAIN_ENGINE == "autograd"
+        with pytest.raises(ValueError):
+            TR.set_train_engine("planed")
+    finally:
+        TR.set_train_engine(old)
+    with pytest.raises(ValueError):
+        A.set_wgrad_impl("trr")
+    net = VideoUNet(**O.TINY.as_reference_kwargs())
+    with pytest.raises(_lib.GcdError, match="GPU"):
+        TP.TrainPlan(net)
+    # a bucketer that is not active (single process) registers nothing; close() is idempotent
+    n0 = len(TP.GRAD_LISTENERS)
+    b = TR.GradBucketer(net.parameters(), None)
+    assert len(TP.GRAD_LISTENERS) == n0
+    b.close()
+    b.close()
