@@ -530,14 +530,19 @@ class TrainPlan:
         self.checkpoint_policy = pol
         self.use_checkpoint = pol != "off"
 
+    @classmethod
+    def contexts_fit(cls, tokens: int, model_channels: int, free_bytes: int) -> bool:
+        """True when the unit contexts of one step (CTX_BYTES_PER_TOKEN_CHANNEL per L0 token and model channel, + 25 %)
+        fit in `free_bytes` with 8 GB to spare — i.e. when nothing needs to be recomputed."""
+        return cls.CTX_BYTES_PER_TOKEN_CHANNEL * tokens * model_channels * 1.25 <= free_bytes - (8 << 30)
+
     def _decide_checkpoint(self, tokens: int) -> None:
         if self.checkpoint_policy != "auto":
             self.use_checkpoint = self.checkpoint_policy == "on"
             return
-        need = self.CTX_BYTES_PER_TOKEN_CHANNEL * tokens * self.unet.model_channels * 1.25
         free, _ = torch.cuda.mem_get_info(self.device)
         free += torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
-        self.use_checkpoint = need > free - (8 << 30)
+        self.use_checkpoint = not self.contexts_fit(tokens, self.unet.model_channels, free)
 
     def zeros(self, m: int, n: int) -> Optional[torch.Tensor]:
         """A zeroed [m, n] view of the step's arena (None when it is exhausted: the caller then allocates)."""

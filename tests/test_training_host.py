@@ -373,3 +373,16 @@ def test_train_engine_switch_and_planned_engine_refuse_loudly():
     assert len(TP.GRAD_LISTENERS) == n0
     b.close()
     b.close()
+
+
+def test_checkpoint_policy_is_a_memory_decision():
+    """TrainPlan.contexts_fit: cfg4's 2 clips (43 008 L0 tokens, 320 channels: 27.5 GB with margin) and 8 clips (110 GB) fit a
+    mostly free 288 GB part and are not recomputed; the same 8 clips do not fit an 80 GB part (the reference's hardware) nor
+    a 288 GB part that has 60 GB left; 8 clips at 64 x 96 latents (440 GB) never do."""
+    from gcd_amd.train_plan import TrainPlan
+    GB = 1 << 30
+    t2, t8 = 28 * 32 * 48, 112 * 32 * 48
+    assert TrainPlan.contexts_fit(t2, 320, 250 * GB) and TrainPlan.contexts_fit(t8, 320, 250 * GB)
+    assert TrainPlan.contexts_fit(t2, 320, 60 * GB) and not TrainPlan.contexts_fit(t8, 320, 60 * GB)
+    assert not TrainPlan.contexts_fit(t8, 320, 80 * GB - 30 * GB)
+    assert not TrainPlan.contexts_fit(112 * 64 * 96, 320, 280 * GB)
