@@ -544,6 +544,14 @@ class TrainPlan:
         free += torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
         self.use_checkpoint = not self.contexts_fit(tokens, self.unet.model_channels, free)
 
+    # a plan is scratch state of ONE network object on one device: copies and pickles of the network do not carry it
+    # (plan_for builds a fresh one on first use)
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
+
     def zeros(self, m: int, n: int) -> Optional[torch.Tensor]:
         """A zeroed [m, n] view of the step's arena (None when it is exhausted: the caller then allocates)."""
         need = (m * n + 3) // 4 * 4
@@ -1144,7 +1152,6 @@ class _PlannedUNet(torch.autograd.Function):
         return (None,) * 8
 
 
-_PLANS: Dict[int, TrainPlan] = {}
 # GCD_TRAIN_GRAPH=1: capture the planned forward and backward passes as two hipGraphs after two eager steps (GraphedPlan)
 import os as _os  # noqa: E402
 USE_GRAPH = _os.environ.get("GCD_TRAIN_GRAPH", "0") == "1"
@@ -1156,12 +1163,16 @@ def set_use_graph(on: bool) -> None:
 
 
 def plan_for(unet: VideoUNet, use_checkpoint: Optional[bool] = None) -> TrainPlan:
-    p = _PLANS.get(id(unet))
+    """The network's plan, created on first use and kept ON the network object (a plain attribute, not a registered
+    sub-module): the flat gradient buffer (4 B per parameter) and the persistent operand forms (4 B per matrix parameter)
+    live exactly as long as the network does — dropping the network drops them (the two reference each other: a cycle the
+    garbage collector takes)."""
+    p = unet.__dict__.get("_gcd_train_plan")
     if p is None or p.unet is not unet:
         p = TrainPlan(unet, use_checkpoint)
         p._anchor = torch.zeros(1, device=p.device, requires_grad=True)
         p.graphed = GraphedPlan(p)
-        _PLANS[id(unet)] = p
+        object.__setattr__(unet, "_gcd_train_plan", p)
     else:
         p.set_checkpoint(use_checkpoint)
     return p

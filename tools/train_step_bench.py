@@ -23,7 +23,7 @@ from bench import build_model  # noqa: E402
 
 def _graph_mode(net):
     from gcd_amd import train_plan as TP
-    p = TP._PLANS.get(id(net))
+    p = net.__dict__.get("_gcd_train_plan")
     return None if p is None or not TP.USE_GRAPH else p.graphed.mode
 
 
