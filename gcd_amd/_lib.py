@@ -15,7 +15,7 @@ _PKG = Path(__file__).resolve().parent
 # tools; the product is the in-tree library next to this file.
 LIB_PATH = Path(os.environ["GCD_AMD_LIB"]).resolve() if os.environ.get("GCD_AMD_LIB") else _PKG / "libgcd_amd.so"
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # GEMM modes / output kinds (mirror include/gcd_amd.h)
 GEMM_PLAIN, GEMM_CONV3X3, GEMM_TEMPORAL3 = 0, 1, 2
@@ -50,6 +50,17 @@ class GemmDesc(C.Structure):
     ]
 
 
+class FfDesc(C.Structure):
+    """gcd_ff_desc (include/gcd_amd.h): the one-kernel FeedForward of the C = 320 level."""
+    _fields_ = [
+        ("X", C.c_void_p), ("ldx", C.c_int64), ("wp", C.c_void_p), ("b1", C.c_void_p), ("b2", C.c_void_p),
+        ("R1", C.c_void_p), ("ldr1", C.c_int64), ("R2", C.c_void_p), ("ldr2", C.c_int64),
+        ("out", C.c_void_p), ("ldo", C.c_int64), ("out_kind", C.c_int32),
+        ("frame_alpha", C.c_void_p), ("rows_per_alpha", C.c_int32), ("s_acc", C.c_float), ("s_r2", C.c_float),
+        ("M", C.c_int32), ("C", C.c_int32), ("hidden", C.c_int32), ("sched", C.c_int32),
+    ]
+
+
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); every symbol include/gcd_amd.h declares
@@ -62,6 +73,10 @@ SIGNATURES = {
     "gcd_gemm_ln_fusable": (_i, [_i, _i, _i, _i]),
     "gcd_gemm_colstats_supported": (_i, [C.POINTER(GemmDesc)]),
     "gcd_gemm_hidden_blocked_supported": (_i, [_i, _i, _i]),
+    "gcd_ff_packed_bytes": (_i64, []),
+    "gcd_ff_pack_f16": (_i, [_vp, _vp, _vp, _vp]),
+    "gcd_ff_fused_supported": (_i, [_i, _i, _i]),
+    "gcd_ff_fused_f16": (_i, [C.POINTER(FfDesc), _vp]),
     "gcd_groupnorm_stats_from_colsums": (_i, [_vp, _i, _vp, _i, _i64, _i64, _f, _vp, _vp]),
     "gcd_linear_smallm_f32": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "gcd_groupnorm_stats": (_i, [_vp, _i64, _i, _vp, _i64, _i, _i64, _i64, _f, _vp, _i, _vp, _vp]),

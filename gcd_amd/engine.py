@@ -239,7 +239,10 @@ class UNetEngine:
 
         def pack_ff(ff):
             w1, b1 = packing.pack_geglu(ff.net[0].proj.weight, ff.net[0].proj.bias)
-            return dict(w1=w1, b1=b1, w2=packing.pack_linear(ff.net[2].weight), b2=_f32(ff.net[2].bias))
+            d = dict(w1=w1, b1=b1, w2=packing.pack_linear(ff.net[2].weight), b2=_f32(ff.net[2].bias))
+            if w1.is_cuda and tuple(w1.shape) == (2560, 320) and tuple(d["w2"].shape) == (320, 1280):
+                d["wp"] = ops.ff_pack(w1, d["w2"])     # the one-kernel FeedForward's fragment-order weight stream
+            return d
 
         def pack_attn(att, q_scale=1.0):
             return dict(wqkv=packing.pack_qkv(att.to_q.weight, att.to_k.weight, att.to_v.weight,
@@ -461,6 +464,17 @@ class UNetEngine:
 
     def _ff(self, F, a16, M, **epi):
         ws = self.ws
+        if "wp" in F and epi.get("ln") is None and ops.ff_fused_ok(M, F["w1"].shape[1], F["w1"].shape[0] // 2) \
+                and epi.get("r1") is not None and (epi.get("frame_alpha") is None or epi.get("r1_blend")) \
+                and (epi.get("r2") is None) == (epi.get("frame_alpha") is None):
+            # FeedForward + residual(s) as ONE launch: the hidden tensor never leaves the CU (ff_fused_kernel.h)
+            kw = dict(r1=epi["r1"], r2=epi.get("r2"), out_kind=epi.get("out_kind", OUT_F32),
+                      frame_alpha=epi.get("frame_alpha"), rows_per_alpha=epi.get("rows_per_alpha", 1))
+            if _ZIGZAG in (1, 2):
+                kw["sched"] = self._next_dir()
+            ops.ff_fused(a16, F["wp"], F["b1"], F["b2"], epi["out"], M=M, **kw)
+            ws.release(a16)
+            return
         hid = ws.alloc((M, F["w1"].shape[0] // 2), torch.float16)
         # the hidden tensor only lives between these two GEMMs: where both run on the ping-pong kernel it
         # is kept tile-blocked ([M/256][N/320][256][160]: whole 128-byte lines per store, §7 of DESIGN.md)

@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (GEMM_CONV3X3, GEMM_PLAIN, GEMM_TEMPORAL3, OUT_F16, OUT_F32, OUT_GEGLU, GemmDesc,
+from ._lib import (GEMM_CONV3X3, GEMM_PLAIN, GEMM_TEMPORAL3, OUT_F16, OUT_F32, OUT_GEGLU, FfDesc, GemmDesc,
                    check)
 
 _zero_pages = {}
@@ -202,6 +202,53 @@ def gemm(a16: torch.Tensor, w16: torch.Tensor, out: torch.Tensor, *, M: int, mod
                 nres=int(r1 is not None) + int(r2 is not None), cin=(conv or {}).get("Cin", K),
                 stride=(conv or {}).get("stride", 1), up=int((conv or {}).get("upsample", 0))):
         check(_lib.load().gcd_gemm_f16(C.byref(d), _stream()), "gcd_gemm_f16")
+    return out
+
+
+# ---- FeedForward(GEGLU) as one kernel (gcd_ff_fused_f16; the C = 320 / hidden = 1280 level) ----------------------------
+# GCD_FF_FUSED=0 keeps the two-GEMM path everywhere (A/B).  The one-kernel form processes 128-token tiles on a persistent
+# grid of one workgroup per CU; below ~4 rounds of tiles the rounding-up of the last round costs more than the fusion
+# saves (tools/ff_fused_probe: 71 vs 39 us at M = 4096), so it is used from FF_FUSED_MIN_TOKENS tokens.
+_FF_FUSED_ON = os.environ.get("GCD_FF_FUSED", "1") != "0"
+FF_FUSED_MIN_TOKENS = int(os.environ.get("GCD_FF_FUSED_MIN_TOKENS", str(4 * 256 * 128)))
+
+
+def ff_fused_ok(M: int, C_: int, hidden: int, enabled: Optional[bool] = None) -> bool:
+    on = _FF_FUSED_ON if enabled is None else enabled
+    return bool(on and M >= FF_FUSED_MIN_TOKENS and _lib.load().gcd_ff_fused_supported(M, C_, hidden))
+
+
+def ff_pack(w1_geglu16: torch.Tensor, w2_16: torch.Tensor) -> torch.Tensor:
+    """The fragment-order weight stream of one FeedForward (gcd_ff_pack_f16): w1 = packing.pack_geglu's fp16
+    [2560, 320], w2 = fp16 [320, 1280].  Once per parameter version."""
+    _need_gpu(w1_geglu16, w2_16)
+    assert w1_geglu16.dtype == w2_16.dtype == torch.float16 and w1_geglu16.is_contiguous() and w2_16.is_contiguous()
+    assert tuple(w1_geglu16.shape) == (2560, 320) and tuple(w2_16.shape) == (320, 1280)
+    lib = _lib.load()
+    wp = torch.empty(int(lib.gcd_ff_packed_bytes()) // 2, device=w1_geglu16.device, dtype=torch.float16)
+    check(lib.gcd_ff_pack_f16(w1_geglu16.data_ptr(), w2_16.data_ptr(), wp.data_ptr(), _stream()), "gcd_ff_pack_f16")
+    return wp
+
+
+def ff_fused(x16: torch.Tensor, wp: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor, out: torch.Tensor, *, M: int,
+             r1: torch.Tensor, r2: Optional[torch.Tensor] = None, out_kind: int = OUT_F32, s_acc: float = 1.0,
+             s_r2: float = 1.0, frame_alpha=None, rows_per_alpha: int = 1, sched: int = 0):
+    """out = s_acc (FF(x16) + r1) + s_r2 r2 in one kernel (gcd_ff_desc); frame_alpha: s_acc = 1 - alpha, s_r2 = alpha."""
+    _need_gpu(x16, wp, b1, b2, out, r1, r2, frame_alpha)
+    assert x16.dtype == torch.float16 and out.dtype == (torch.float32 if out_kind == OUT_F32 else torch.float16)
+    d = FfDesc()
+    d.X, d.ldx, d.wp, d.b1, d.b2 = x16.data_ptr(), _ld(x16), wp.data_ptr(), b1.data_ptr(), b2.data_ptr()
+    d.R1, d.ldr1 = r1.data_ptr(), _ld(r1)
+    if r2 is not None:
+        d.R2, d.ldr2 = r2.data_ptr(), _ld(r2)
+    d.out, d.ldo, d.out_kind = out.data_ptr(), _ld(out), out_kind
+    if frame_alpha is not None:
+        d.frame_alpha, d.rows_per_alpha = frame_alpha.data_ptr(), rows_per_alpha
+    d.s_acc, d.s_r2 = s_acc, s_r2
+    d.M, d.C, d.hidden, d.sched = M, 320, 1280, int(sched)
+    with _Timed("gemm", 2.0 * M * 320 * 3840, M=M, N=320, K=3840, mode=GEMM_PLAIN, out_kind=out_kind,
+                nres=1 + int(r2 is not None), cin=3840, stride=1, up=0, fused_ff=1):
+        check(_lib.load().gcd_ff_fused_f16(C.byref(d), _stream()), "gcd_ff_fused_f16")
     return out
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GCD_AMD_ABI_VERSION 7
+#define GCD_AMD_ABI_VERSION 8
 
 /* ---- library ------------------------------------------------------------------------------ */
 int gcd_abi_version(void);
@@ -187,6 +187,42 @@ int gcd_gemm_colstats_supported(const gcd_gemm_desc* desc);
  * and whose second Linear has N_out columns can keep its hidden tensor tile-blocked (out_blocked on the
  * first GEMM, a_blocked on the second): both launches must land on the ping-pong kernel.          */
 int gcd_gemm_hidden_blocked_supported(int M, int N_geglu, int N_out);
+
+/* ---- FeedForward(GEGLU) as ONE kernel (ABI v8; the C = 320 / hidden = 1280 level) ------------------------------
+ * out[M, 320] = s_acc * ( W2 . (value * gelu(gate)) + b2 + R1 ) + s_r2 * R2,   value | gate = W1 . x + b1,
+ * the 1280-wide hidden tensor rounded to fp16 once (the rounding point of the two-GEMM path) and never written to
+ * memory: per 128-token tile the workgroup streams W1 / W2 through LDS in 32-hidden-unit chunks, keeps the tile's x
+ * fragments in registers and the output accumulators — initialised with R1 — in the accumulator file
+ * (gcd_amd/csrc/ff_fused_kernel.h).  Replaces, for that level, FeedForward.forward (attention.py:87-121) together with
+ * the residual adds around it (attention.py:566-572, video_attention.py:109-140) and the AlphaBlender
+ * (util.py:364-368; frame_alpha: s_acc := 1 - alpha, s_r2 := alpha per `rows_per_alpha` rows, with R1 inside the
+ * blended term — gcd_gemm_desc's r1_blend form).  Same arithmetic as gcd_gemm_f16(GCD_OUT_GEGLU) + gcd_gemm_f16 up to
+ * fp32 summation order (R1 enters the accumulation first).                                                          */
+typedef struct gcd_ff_desc {
+  const void* X;            /* fp16 [M, 320] LayerNorm output, leading dimension ldx (elements)           */
+  int64_t ldx;
+  const void* wp;           /* gcd_ff_pack_f16 output (gcd_ff_packed_bytes() bytes)                        */
+  const float* b1;          /* [2560] in the GEGLU row order of GCD_OUT_GEGLU (16 value / 16 gate)         */
+  const float* b2;          /* [320]                                                                        */
+  const float* R1;          /* fp32 [M, 320] residual, REQUIRED; out may alias it                           */
+  int64_t ldr1;
+  const float* R2;          /* fp32 [M, 320] or NULL; out may alias it                                      */
+  int64_t ldr2;
+  void* out;                /* fp32 [M, 320]; fp16 allowed (GCD_OUT_F16) when R2 is given                   */
+  int64_t ldo;
+  int32_t out_kind;         /* GCD_OUT_F32 / GCD_OUT_F16                                                    */
+  const float* frame_alpha; /* optional [ceil(M / rows_per_alpha)]                                          */
+  int32_t rows_per_alpha;   /* multiple of 32                                                               */
+  float s_acc, s_r2;        /* used when frame_alpha == NULL                                                */
+  int32_t M, C, hidden;     /* C = 320, hidden = 1280                                                       */
+  int32_t sched;            /* bit 0: walk the tiles from the end (as gcd_gemm_desc.sched)                  */
+} gcd_ff_desc;
+int64_t gcd_ff_packed_bytes(void);
+/* w1: fp16 [2560, 320] in GCD_OUT_GEGLU row order, w2: fp16 [320, 1280] -> wp, the weights in MFMA-fragment order
+ * (per 32-hidden-unit chunk 40 W1 fragments + 20 W2 fragments of 1 KB).  Once per parameter version.                */
+int gcd_ff_pack_f16(const void* w1, const void* w2, void* wp, void* stream);
+int gcd_ff_fused_supported(int M, int C, int hidden);
+int gcd_ff_fused_f16(const gcd_ff_desc* desc, void* stream);
 
 /* y[M,N] (fp32) = [y +] act_out( act_in(x[M,K]) @ W[N,K]^T + b ), fp32 weights, any M >= 1 (rows are processed 32 at a time).
  * act flags: bit0 = SiLU on input, bit1 = SiLU on output, bit2 = accumulate into y.

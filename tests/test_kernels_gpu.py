@@ -326,6 +326,75 @@ def test_gemm_geglu(gpu, M, C):
     assert e < TOL_F16, f"geglu rel-L2 {e:.3e}"
 
 
+@pytest.mark.parametrize("M,form", [(128 * 256 + 77, "plain"), (4096, "blend32"), (9216 * 2, "blend16"), (1, "plain")])
+def test_ff_fused_one_kernel(gpu, M, form):
+    """FeedForward(GEGLU) of the C = 320 level as ONE kernel (gcd_ff_fused_f16, ff_fused_kernel.h): LayerNorm'd tokens in,
+    residual stream out, the hidden tensor never in memory — against the fp32 torch FeedForward (attention.py:87-121) with
+    the residual / AlphaBlender forms of video_attention.py:109-140, util.py:364-368, and against the library's two-GEMM
+    path (same fp16 rounding point of the hidden tensor: agreement to fp32 summation order).  Sizes: more than one round of
+    128-token tiles with a ragged last tile, two frames of alphas, one token."""
+    from gcd_amd import ops, packing
+    g = _gen(611)
+    C, H = 320, 1280
+    x = _h(torch.randn(M, C, generator=g))
+    w1 = _h(torch.randn(2 * H, C, generator=g) / math.sqrt(C))
+    b1 = torch.randn(2 * H, generator=g) * 0.5
+    w2 = _h(torch.randn(C, H, generator=g) / math.sqrt(H))
+    b2 = torch.randn(C, generator=g)
+    r1 = torch.randn(M, C, generator=g)
+    r2 = torch.randn(M, C, generator=g)
+    rows_per_alpha = 9216 if form == "blend16" else 2048
+    alpha = torch.rand((M + rows_per_alpha - 1) // rows_per_alpha, generator=g)
+    h = x @ w1.t() + b1
+    hid = _h(h[:, :H] * F.gelu(h[:, H:]))          # the hidden tensor is an fp16 MFMA operand in both HIP paths
+    ff = hid @ w2.t() + b2
+    if form == "plain":
+        ref = ff + r1
+    else:
+        a = alpha.repeat_interleave(rows_per_alpha)[:M, None]
+        ref = (1 - a) * (ff + r1) + a * r2
+    w1p, b1p = packing.pack_geglu(w1.to(gpu), b1.to(gpu))
+    w2p = w2.half().to(gpu)
+    wp = ops.ff_pack(w1p, w2p)
+    xg, r1g, r2g, b2g, ag = x.half().to(gpu), r1.to(gpu), r2.to(gpu), b2.to(gpu), alpha.to(gpu)
+    out = torch.empty(M, C, device=gpu, dtype=torch.float16 if form == "blend16" else torch.float32)
+    two = torch.empty_like(out)
+    hid16 = torch.empty(M, H, device=gpu, dtype=torch.float16)
+    ops.gemm(xg, w1p, hid16, M=M, bias=b1p, out_kind=ops.OUT_GEGLU)
+    if form == "plain":
+        ops.ff_fused(xg, wp, b1p, b2g, out, M=M, r1=r1g)
+        ops.gemm(hid16, w2p, two, M=M, bias=b2g, r1=r1g)
+    else:
+        kind = ops.OUT_F16 if form == "blend16" else ops.OUT_F32
+        ops.ff_fused(xg, wp, b1p, b2g, out, M=M, r1=r1g, r2=r2g, out_kind=kind, frame_alpha=ag, rows_per_alpha=rows_per_alpha)
+        ops.gemm(hid16, w2p, two, M=M, bias=b2g, r1=r1g, r2=r2g, out_kind=kind, frame_alpha=ag,
+                 rows_per_alpha=rows_per_alpha, r1_blend=True)
+    torch.cuda.synchronize()
+    e = rel_l2(out.float(), ref)
+    e2 = rel_l2(out.float(), two.float())
+    print(f"fused FeedForward M = {M} {form}: vs fp32 torch {e:.2e}, vs the two-GEMM path {e2:.2e}")
+    assert e < (TOL_F16 if form == "blend16" else 3e-4), f"rel-L2 {e:.3e}"
+    assert e2 < (6e-4 if form == "blend16" else 5e-5), f"vs two-GEMM path {e2:.3e}"
+    # in place (out aliases the residual it initialises the accumulators with), as the engine calls it
+    if form == "plain":
+        inpl = r1g.clone()
+        ops.ff_fused(xg, wp, b1p, b2g, inpl, M=M, r1=inpl)
+        torch.cuda.synchronize()
+        assert torch.equal(inpl, out)
+
+
+def test_ff_fused_refuses_what_it_cannot_do(gpu):
+    from gcd_amd import ops, _lib
+    x = torch.zeros(256, 320, device=gpu, dtype=torch.float16)
+    wp = torch.zeros(int(_lib.load().gcd_ff_packed_bytes()) // 2, device=gpu, dtype=torch.float16)
+    b1, b2 = torch.zeros(2560, device=gpu), torch.zeros(320, device=gpu)
+    out = torch.zeros(256, 320, device=gpu)
+    with pytest.raises(Exception, match="rows_per_alpha"):
+        ops.ff_fused(x, wp, b1, b2, out, M=256, r1=out, r2=out, frame_alpha=torch.zeros(26, device=gpu), rows_per_alpha=10)
+    assert not ops.ff_fused_ok(10 ** 6, 640, 2560, enabled=True) and ops.ff_fused_ok(10 ** 6, 320, 1280, enabled=True)
+    assert not ops.ff_fused_ok(1000, 320, 1280, enabled=True)       # too few tiles to pay
+
+
 def test_feedforward_tile_blocked_hidden(gpu, gemm_impl):
     """GEGLU output written tile-blocked ([M/256][N/320][256][160]) and consumed that way by the second
     Linear: bit-identical to the row-major pair (same products, same accumulation order), the block
