@@ -24,7 +24,7 @@
 // iteration i (~2 per MFMA): a wave's own VALU work issues in the shadow of its own MFMAs, nothing else does on gfx950
 // (tools/issue_probe).  Every MFMA and every GELU operation is pinned (volatile asm): program order is issue order —
 // left to hipcc the MFMA results land in the accumulator file and come back through v_accvgpr_read, and the polynomial
-// is emitted in clumps of 10-18 instructions between MFMA pairs.  LDS-DMA of W1(i+1) and W2(i): one piece every third
+// is emitted in clumps of 10-18 instructions between MFMA pairs.  LDS-DMA of W1(i+1) and W2(i): one piece every second
 // slot; ONE `vmcnt(0)` + `s_barrier` per iteration; fragments are read in batches of FB slots, one batch ahead, with ONE
 // wait per batch.  Measured: tools/ff_fused_probe, profiles/r06_ff_fused_probe.txt.
 #pragma once
@@ -70,12 +70,36 @@ constexpr int FF_OFF_B2 = FF_OFF_B1 + 2560 * 4, FF_SMEM = FF_OFF_B2 + 320 * 4;  
 
 // Probe knobs (tools/ff_fused_probe builds one binary per setting).  FF_ABL bits give WRONG results by design: 1 no LDS-DMA
 // in the loop, 2 no GELU operations, 4 no vmcnt / barrier in the loop, 8 no GEMM1 MFMAs, 16 no GEMM2 MFMAs, 32 no epilogue
-// stores, 64 no fragment reads in the loop.  FF_FB: slots per fragment batch (3, 5 or 6).
+// stores, 64 no fragment reads in the loop, 128 / 256 / 512 lane-linear (fully coalesced, wrong) addresses for the stores /
+// the residual loads / the X loads: what the 16-rows-x-64-B access shape of the accumulator layout costs.  FF_FB: slots per fragment batch (3, 5 or 6).  FF_DMA_EVERY: a DMA piece every
+// n-th slot from slot 1 (3: the last one at slot 43, eleven slots before the wait; 2, the default: at slot 29 — -1 %).
+// FF_KERNEL: the kernel's name — tools/ff_fused_probe builds its own instantiations beside the library's and must not
+// share their symbols (a second registration of the same host stub shadows the first).
+#ifndef FF_KERNEL
+#define FF_KERNEL ff_fused_kernel
+#endif
 #ifndef FF_ABL
 #define FF_ABL 0
 #endif
 #ifndef FF_FB
 #define FF_FB 5
+#endif
+// FF_R1MOD: cache-policy modifiers of the residual loads (probe)
+#if !defined(FF_R1MODE) || FF_R1MODE == 0
+#define FF_R1MOD ""
+#elif FF_R1MODE == 1
+#define FF_R1MOD " nt"
+#elif FF_R1MODE == 2
+#define FF_R1MOD " sc1"
+#else
+#define FF_R1MOD " sc0 sc1"
+#endif
+#ifndef FF_DMA_EVERY
+#define FF_DMA_EVERY 2
+#endif
+// FF_STAGGER n: workgroup b starts ((b >> 3) & 7) * n * 8128 cycles late (b & 7 is its XCD: neighbours within an XCD are spread) (probe: do the tile-boundary HBM bursts of the CUs coincide?)
+#ifndef FF_STAGGER
+#define FF_STAGGER 0
 #endif
 #ifdef FF_TIMING
 #define FF_STAMP(idx) do { if (blockIdx.x == 0 && t == 0 && p.dbg) p.dbg[(tile0 / gridDim.x) * 64 + (idx)] = __builtin_readcyclecounter(); } while (0)
@@ -106,12 +130,12 @@ struct FfGelu<15> {
 // 16 bytes of the residual straight into the accumulator file; hipcc does not count an asm load (the caller's vmcnt(0) does)
 template <int OFF>
 __device__ __forceinline__ void ff_load_acc(f32x4& dst, const float* src) {
-  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(dst) : "v"(src), "n"(OFF) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" FF_R1MOD : "=a"(dst) : "v"(src), "n"(OFF) : "memory");
 }
 
 // EPI: 0 = out = sa (acc + b2 + R1), fp32; 1 = ... + sr2 R2 (AlphaBlender), fp32; 2 = the same with an fp16 result
 template <int T, int DEG, int EPI>
-__global__ __launch_bounds__(256) void ff_fused_kernel(const FfK p) {
+__global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -129,6 +153,11 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(const FfK p) {
   const __amdgpu_buffer_rsrc_t rsrcW =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, (FF_NCH + 1) * FF_CHUNK_BYTES, 0x00020000);
   const unsigned lane16 = (unsigned)lane * 16u;
+  // the result leaves through a range-checked buffer descriptor: rows >= M are dropped by the hardware — no branch, no
+  // exec mask, every wave issues exactly 20 T stores per tile (the counted wait at the tile boundary relies on that, and so
+  // does hipcc's own count for the loads it tracks across them)
+  const __amdgpu_buffer_rsrc_t rsrcO = __builtin_amdgcn_make_buffer_rsrc(
+      p.out, 0, (int)((int64_t)p.M * p.ldo * (OUT16 ? 2 : 4)), 0x00020000);
   auto dma = [&](int goff, int lds_off) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (GCD_AS3 void*)(smem + lds_off), 16, (int)lane16, goff, 0, 0);
   };
@@ -142,13 +171,17 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(const FfK p) {
   auto load_x = [&](f16x8 (&dst)[T][10], int mb) {
 #pragma unroll
     for (int tb = 0; tb < T; ++tb) {
-      const f16* src = p.X + (int64_t)min(mb + 16 * tb + r, p.M - 1) * p.ldx + 8 * g;
+      const f16* src = (FF_ABL & 512) ? p.X + (int64_t)min(mb + 16 * tb, p.M - 16) * p.ldx + lane * 8
+                                      : p.X + (int64_t)min(mb + 16 * tb + r, p.M - 1) * p.ldx + 8 * g;
 #pragma unroll
-      for (int ks = 0; ks < 10; ++ks) dst[tb][ks] = *(const f16x8*)(src + 32 * ks);
+      for (int ks = 0; ks < 10; ++ks) dst[tb][ks] = *(const f16x8*)(src + ((FF_ABL & 512) ? 512 : 32) * ks);
     }
   };
   // LDS buffer parity: chunk i of the current tile sits in W1 buffer (i + par) & 1, W2 buffer (i + par) & 1; a tile has 41
   // iterations, so the next tile's W1(0) — DMA'd during this tile's last iteration — lands in buffer (41 + par) & 1 = par ^ 1
+  if constexpr (FF_STAGGER > 0) {
+    for (int k = 0; k < (int)((blockIdx.x >> 3) & 7) * FF_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
+  }
   int par = 0;
   if ((int)blockIdx.x < ntiles) {
     // ---- first tile of this workgroup: W1(0) -> buffer 0, X fragments ----
@@ -158,12 +191,22 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(const FfK p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
+  // hipcc counts the X loads but not the asm loads the first iteration issues between its MFMAs: left to itself it waits for
+  // X inside that iteration with counts (vmcnt(9) ...) that also drain the residual loads and the previous tile's stores —
+  // 9 memory instructions in flight per wave instead of 60 (measured: 17 000 cycles for the first 20 slots of every tile).
+  // The pin makes it wait HERE, where the data is in (the vmcnt(0) above; the counted wait at every tile boundary below).
+  auto pin_x = [&]() {
+#pragma unroll
+    for (int tb = 0; tb < T; ++tb)
+      asm volatile("" : "+v"(X[tb][0]), "+v"(X[tb][1]), "+v"(X[tb][2]), "+v"(X[tb][3]), "+v"(X[tb][4]), "+v"(X[tb][5]),
+                   "+v"(X[tb][6]), "+v"(X[tb][7]), "+v"(X[tb][8]), "+v"(X[tb][9]));
+  };
+  pin_x();
 
   for (int tile0 = blockIdx.x; tile0 < ntiles; tile0 += gridDim.x) {
     const int m_base = tile_of(tile0) * TILE + wave * (16 * T);
     const bool has_next = tile0 + (int)gridDim.x < ntiles;
     const int m_next = has_next ? tile_of(tile0 + gridDim.x) * TILE + wave * (16 * T) : m_base;
-    const bool full = m_base + 16 * T <= p.M;      // every row of this wave's tile is a row of the problem
     FF_STAMP(0);
     f32x4 out[20][T];
     f32x4 aG[4][T];
@@ -182,7 +225,9 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(const FfK p) {
     for (int k = 0; k < 8 * T; ++k) e_va[k] = e_g[k] = e_xc[k] = e_u[k] = e_p[k] = 0.f;
     const float* r1src[T];
 #pragma unroll
-    for (int tb = 0; tb < T; ++tb) r1src[tb] = p.R1 + (int64_t)min(m_base + 16 * tb + r, p.M - 1) * p.ldr1 + 4 * g;
+    for (int tb = 0; tb < T; ++tb)
+      r1src[tb] = (FF_ABL & 256) ? p.R1 + (int64_t)min(m_base + 16 * tb, p.M - 16) * p.ldr1 + lane * 4
+                                 : p.R1 + (int64_t)min(m_base + 16 * tb + r, p.M - 1) * p.ldr1 + 4 * g;
 
     // ---- the GELU of a chunk as single VALU operations placed one by one behind the MFMAs ----
     // Element k (0 .. 8T-1): hidden half k / (4T), token block (k >> 2) % T, accumulator register k & 3.  Elements are
@@ -252,11 +297,12 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(const FfK p) {
       sa = 1.0f - al;
       sr2 = al;
     }
-    f32x4 q2[4][T];      // R2 vectors of channel blocks cb - 1 .. cb + 2 while block cb - 2 is stored (a ring of four)
+    f32x4 q2[8][T];      // R2 vectors of channel blocks cb - 1 .. cb + 6 while block cb - 2 is stored (a ring of eight:
+                         // the loads are six slots old when hipcc's counted wait for them comes)
     auto fetch_r2 = [&](const int cb) {
 #pragma unroll
       for (int tb = 0; tb < T; ++tb)
-        q2[cb % 4][tb] = *(const f32x4*)(p.R2 + (int64_t)min(m_base + 16 * tb + r, p.M - 1) * p.ldr2 + 16 * cb + 4 * g);
+        q2[cb % 8][tb] = *(const f32x4*)(p.R2 + (int64_t)min(m_base + 16 * tb + r, p.M - 1) * p.ldr2 + 16 * cb + 4 * g);
     };
     auto store_cb = [&](auto Cb) {
       constexpr int cb = decltype(Cb)::value;
@@ -271,16 +317,19 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(const FfK p) {
         const int m = m_base + 16 * tb + r;
         asm volatile("" : "+a"(out[cb][tb]));      // read it HERE, 2 T MFMAs behind its last one, not right behind that
         f32x4 v = (out[cb][tb] + bv) * sa;
-        if constexpr (has2) v += sr2 * q2[cb % 4][tb];
-        if (full || m < p.M) {      // (`full` is wave-uniform: a full wave issues exactly 20 T stores, which the counted wait below relies on)
-          if constexpr (OUT16) {
-            f16x4 o;
+        if constexpr (has2) v += sr2 * q2[cb % 8][tb];
+        if constexpr ((FF_ABL & 128) != 0) {
+          *(f32x4*)((float*)p.out + (int64_t)(m_base + 16 * tb) * p.ldo + cb * 256 + lane * 4) = v;
+        } else if constexpr (OUT16) {
+          f16x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (f16)v[e];
-            *(f16x4*)((f16*)p.out + (int64_t)m * p.ldo + 16 * cb + 4 * g) = o;
-          } else {
-            *(f32x4*)((float*)p.out + (int64_t)m * p.ldo + 16 * cb + 4 * g) = v;
-          }
+          for (int e = 0; e < 4; ++e) o[e] = (f16)v[e];
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsrcO,
+                                                    (int)((m * (int)p.ldo + 16 * cb + 4 * g) * 2), 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrcO,
+                                                     (int)((m * (int)p.ldo + 16 * cb + 4 * g) * 4), 0, 0);
         }
       }
     };
@@ -322,13 +371,13 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(const FfK p) {
           load_x(Xn, m_next);
         }
         if constexpr (has2) {
-          fetch_r2(0);
-          fetch_r2(1);
+          ff_static_for<0, 6>([&](auto Cb) { fetch_r2(decltype(Cb)::value); });
         }
       }
       if constexpr (KIND == 2) {      // the tail of chunk 39's GELU (no MFMAs left to put it behind), then H(39) -> GEMM2's operand
         ff_static_for<0, ORG + 1>([&](auto Mm) { after_mfma(Kind, Mm); });
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // H(39) was just written by VALU moves; GEMM2 reads it next
+        FF_STAMP(20);
       }
       ff_static_for<(KIND == 2 ? 40 - FB : 0), 60>([&](auto S) {
         constexpr int s = decltype(S)::value;
@@ -367,7 +416,11 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(const FfK p) {
           constexpr int rb = 2 * (s / 20) + (s & 1), ks = (s % 20) / 2;
           if constexpr (KIND == 0 && s < 20) {      // the residual of channel block s -> accumulators (landed by this iteration's vmcnt(0))
 #pragma unroll
-            for (int tb = 0; tb < T; ++tb) ff_load_acc<s * 64>(out[s][tb], r1src[tb]);
+            for (int tb = 0; tb < T; ++tb) {
+              if constexpr ((FF_ABL & 1024) != 0) out[s][tb] = f32x4{0.f, 0.f, 0.f, 0.f};      // (probe: no residual loads)
+              else if constexpr ((FF_ABL & 256) != 0) ff_load_acc<0>(out[s][tb], r1src[tb] + s * 256);
+              else ff_load_acc<s * 64>(out[s][tb], r1src[tb]);
+            }
           }
           ff_static_for<0, T>([&](auto Tb) {
             constexpr int tb = decltype(Tb)::value;
@@ -394,21 +447,28 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(const FfK p) {
           });
           if constexpr (KIND == 2) {
             if constexpr (cb >= 2) store_cb(std::integral_constant<int, cb - 2>{});
-            if constexpr (cb + 2 < 20 && has2) fetch_r2(cb + 2);      // into the ring slot the store above just freed
+            if constexpr (cb + 6 < 20 && has2) fetch_r2(cb + 6);      // into the ring slot the store above just freed
           }
         }
-        // LDS-DMA: W1(i+1) pieces at slots 1, 4, .., 28; W2(i) pieces at slots 31, .., 43
+        // LDS-DMA: the 10 W1(i+1) pieces, then the 5 W2(i) pieces of this wave, one every FF_DMA_EVERY slots from slot 1
         if constexpr ((FF_ABL & 1) != 0 || KIND == 2) {
-        } else if constexpr (s % 3 == 1 && s < 30) {
-          constexpr int n = s / 3;
+        } else if constexpr (s % FF_DMA_EVERY == 1 && s < 10 * FF_DMA_EVERY) {
+          constexpr int n = s / FF_DMA_EVERY;
           dma(gsrc1 + (wave * 10 + n) * 1024, w1dst + (wave * 10 + n) * 1024);
-        } else if constexpr (s % 3 == 1 && s < 45) {
-          constexpr int n = (s - 30) / 3;
+        } else if constexpr (s % FF_DMA_EVERY == 1 && s < 15 * FF_DMA_EVERY) {
+          constexpr int n = s / FF_DMA_EVERY - 10;
           dma(gsrc2 + (wave * 5 + n) * 1024, w2dst + (wave * 5 + n) * 1024);
         }
+        if constexpr (KIND == 0 && s == 20) FF_STAMP(10);
+        if constexpr (KIND == 0 && s == 40) FF_STAMP(11);
+        if constexpr (KIND == 2 && s == 40) FF_STAMP(21);
+        if constexpr (KIND == 2 && s == 50) FF_STAMP(22);
         if constexpr (s == BSLOT && (FF_ABL & 4) == 0 && KIND != 2) {
+          if constexpr (KIND == 0) FF_STAMP(12);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if constexpr (KIND == 0) FF_STAMP(13);
           __builtin_amdgcn_s_barrier();
+          if constexpr (KIND == 0) FF_STAMP(14);
         }
       });
       if constexpr (KIND == 2) {
@@ -425,26 +485,17 @@ __global__ __launch_bounds__(256) void ff_fused_kernel(const FfK p) {
     FF_STAMP(4);
     // Tile boundary: the next tile's W1(0) pieces and X fragments were requested BEFORE this tile's stores; loads return in
     // order and stores share the counter, so "at most the newest 20 T stores outstanding" = everything older has
-    // landed.  A ragged wave may have skipped stores: it drains.  Then the barrier: every wave's pieces are in, and every
+    // landed (the stores are range-checked buffer stores: every wave issues all of them).  Then the barrier: every wave's pieces are in, and every
     // wave is past its last read of the W2 buffer the next tile's first iteration overwrites.
-    if (full) {
-      if constexpr (T == 2) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if constexpr (T == 2) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     FF_STAMP(5);
 #pragma unroll
     for (int tb = 0; tb < T; ++tb)
 #pragma unroll
       for (int ks = 0; ks < 10; ++ks) X[tb][ks] = Xn[tb][ks];
-    // hipcc counts the X loads but not the asm loads the next first iteration issues between its MFMAs: left to itself it
-    // waits for X with a count that also drains those.  The pin makes it wait HERE (the data is in: see above).
-#pragma unroll
-    for (int tb = 0; tb < T; ++tb)
-      asm volatile("" : "+v"(X[tb][0]), "+v"(X[tb][1]), "+v"(X[tb][2]), "+v"(X[tb][3]), "+v"(X[tb][4]), "+v"(X[tb][5]),
-                   "+v"(X[tb][6]), "+v"(X[tb][7]), "+v"(X[tb][8]), "+v"(X[tb][9]));
+    pin_x();
     par ^= 1;
   }
 }

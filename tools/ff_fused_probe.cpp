@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <vector>
 
+#define FF_KERNEL ff_fused_kernel_probe      // not the library's instantiations (same template, same arguments)
 #include "ff_fused_kernel.h"
 
 #define CK(x)                                                                            \
@@ -68,17 +69,18 @@ __global__ void cmp_kernel(const float* a, const float* b, size_t n, unsigned* r
   atomicAdd(&sums[1], sb);
 }
 
+static int g_grid = 256;
 template <int T, int DEG>
 static float run_fused(const FfK& k, hipStream_t st, int iters, hipEvent_t e0, hipEvent_t e1) {
   static bool opted = false;
   if (!opted) {
-    CK(hipFuncSetAttribute((const void*)ff_fused_kernel<T, DEG, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_SMEM));
+    CK(hipFuncSetAttribute((const void*)ff_fused_kernel_probe<T, DEG, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_SMEM));
     opted = true;
   }
   std::vector<float> t;
   for (int it = 0; it < iters + 2; ++it) {
     CK(hipEventRecord(e0, st));
-    ff_fused_kernel<T, DEG, 0><<<256, 256, FF_SMEM, st>>>(k);
+    ff_fused_kernel_probe<T, DEG, 0><<<g_grid, 256, FF_SMEM, st>>>(k);
     CK(hipEventRecord(e1, st));
     CK(hipEventSynchronize(e1));
     CK(hipGetLastError());
@@ -93,6 +95,7 @@ static float run_fused(const FfK& k, hipStream_t st, int iters, hipEvent_t e0, h
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 28 * 72 * 128;
   const int iters = argc > 2 ? atoi(argv[2]) : 9;
+  g_grid = argc > 3 ? atoi(argv[3]) : 256;      // workgroups of the fused kernel (fewer: is a tile boundary slower when every CU is at one?)
   hipStream_t st;
   CK(hipStreamCreate(&st));
   hipEvent_t e0, e1;
@@ -265,6 +268,11 @@ int main(int argc, char** argv) {
         printf("   tile %d: setup %llu | first iteration %llu | 39 iterations %llu (%llu each) | last iteration + stores %llu | "
                "boundary wait + barrier %llu | total %llu\n",
                tl, q[1] - q[0], q[2] - q[1], q[3] - q[2], (q[3] - q[2]) / 39, q[4] - q[3], q[5] - q[4], q[5] - q[0]);
+        if (q[14])
+          printf("           first iteration: slots 0-19 (+ residual loads) %llu | 20-39 %llu | 40-53 %llu | vmcnt(0) %llu | barrier %llu | rest %llu"
+                 "   last iteration: loads + GELU tail %llu | slots 40-49 %llu | 50-59 %llu\n",
+                 q[10] - q[1], q[11] - q[10], q[12] - q[11], q[13] - q[12], q[14] - q[13], q[2] - q[14], q[21] - q[3], q[22] - q[21],
+                 q[4] - q[22]);
       }
     }
 #endif
