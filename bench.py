@@ -230,6 +230,199 @@ def _pmc_traffic():
                                            "(FETCH x2 per the gfx950 note of MI355X_MICROARCH.md)")
 
 
+TRAIN_ALG_TFLOP = 37.593      # one fine-tune step at cfg4's per-GPU shape: 12.531 forward x 3
+
+
+class _AbiCallCounter:
+    """Counts the C-ABI calls of one step (every `gcd_*` entry point of both libraries launches one kernel — a few
+    launch two: split-K reduce, two-pass statistics).  rocprofv3's dispatch count of the same command is the exact
+    figure (profiles/r06_train_kernel_stats.txt)."""
+
+    def __init__(self):
+        from gcd_amd import _lib
+        self.libs = [(_lib.load(), _lib.SIGNATURES), (_lib.load_train(), _lib.TRAIN_SIGNATURES)]
+        self.n = 0
+        self.saved = []
+
+    def __enter__(self):
+        skip = ("gcd_last_error", "gcd_abi_version", "gcd_train_abi_version", "gcd_tune_set", "gcd_event_", "gcd_stream_",
+                "gcd_graph_", "_bytes", "_supported", "_fusable", "_floats", "gcd_device_info")
+        for lib, sigs in self.libs:
+            for name in sigs:
+                if any(k in name for k in skip):
+                    continue
+                fn = getattr(lib, name)
+                self.saved.append((lib, name, fn))
+
+                def wrap(*a, _fn=fn):
+                    self.n += 1
+                    return _fn(*a)
+                setattr(lib, name, wrap)
+        return self
+
+    def __exit__(self, *exc):
+        for lib, name, fn in self.saved:
+            setattr(lib, name, fn)
+        return False
+
+
+def train_leg(dev, dtype: str, steps: int, clips: int = 2, latent=(32, 48)):
+    """BASELINE.json cfg4 on ONE GPU: the fine-tune step (StandardDiffusionLoss forward + backward + Adam,
+    sgm/modules/diffusionmodules/loss.py:115-273, sgm/models/diffusion.py:412-431) of the full-width Kubric VideoUNet on
+    `clips` clips x 14 frames of 32 x 48 latents (configs/train_kubric_max90.yaml:209-234), GEMM operands in `dtype`.
+    Wall time per phase (median of `steps`), algorithmic TFLOP/s, C-ABI calls of one step."""
+    from gcd_amd import autograd_ops as AO
+    from gcd_amd import training as TR
+    AO.set_train_dtype(dtype)
+    AO.PACK.clear()
+    T = 14
+    h, w = latent
+    BT = clips * T
+    net = build_model(dev, seed=0).train()
+    den = TR.TrainDenoiser({"target": "gcd_amd.denoiser_scaling.VScalingWithEDMcNoise"}, use_checkpoint=None)
+    loss_fn = TR.StandardDiffusionLoss(
+        sigma_sampler_config={"target": "gcd_amd.training.EDMSampling", "params": {"p_mean": 1.0, "p_std": 1.6}},
+        loss_weighting_config={"target": "gcd_amd.training.EDMWeighting", "params": {"sigma_data": 1.0}},
+        focus_top=0.1, focus_steps=5000, batch2model_keys=["image_only_indicator", "num_video_frames"])
+    opt = TR.AdamHIP(net.parameters(), lr=2e-5)
+    g = torch.Generator(device=dev).manual_seed(1)
+    x0 = torch.randn(BT, 4, h, w, generator=g, device=dev)
+    cond = {"crossattn": torch.randn(BT, 1, 1024, generator=g, device=dev),
+            "concat": torch.randn(BT, 4, h, w, generator=g, device=dev) * 0.8,
+            "vector": torch.randn(BT, 896, generator=g, device=dev).clamp(-1, 1)}
+    batch = {"global_step": 2500, "num_video_frames": T, "image_only_indicator": torch.zeros(clips, T, device=dev)}
+    scale = 1024.0
+    times, calls, finite = [], 0, True
+    try:
+        for it in range(steps + 2):
+            counter = _AbiCallCounter() if it == 1 else None      # the second step: packing and planning are done
+            if counter:
+                counter.__enter__()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            loss = loss_fn._forward(net, den, cond, x0, batch).mean()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            opt.zero_grad()
+            (loss * scale).backward()
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter()
+            opt.step(grad_scale=1.0 / scale)
+            torch.cuda.synchronize(dev)
+            t3 = time.perf_counter()
+            if counter:
+                counter.__exit__()
+                calls = counter.n
+            elif it >= 2:
+                times.append((t1 - t0, t2 - t1, t3 - t2))
+            finite = finite and bool(torch.isfinite(loss))
+    finally:
+        AO.set_train_dtype("fp16")
+        AO.PACK.clear()
+    f, b, o = (sorted(t[i] for t in times)[len(times) // 2] for i in range(3))
+    tf = TRAIN_ALG_TFLOP * (h * w) / (32 * 48) * clips / 2
+    step = f + b + o
+    res = {"gemm_operands": dtype, "clips": clips, "frames": BT, "latent": [h, w], "forward_s": round(f, 4),
+           "backward_s": round(b, 4), "adam_s": round(o, 4), "step_s": round(step, 4), "algorithmic_tflop": round(tf, 2),
+           "tflops": round(tf / step, 1), "frac_of_2p5_pflops": round(tf / step / 2500.0, 4),
+           "c_abi_calls_per_step": calls, "loss_finite": finite, "engine": TR.TRAIN_ENGINE,
+           "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}
+    del net, opt
+    torch.cuda.empty_cache()
+    return res
+
+
+def train_parity(dev, dtype: str):
+    """The same step against the UNMODIFIED reference's fp32 autograd run (tests/golden/train_kubric_32x48.pt, generated
+    by oracle/make_golden_cfg4.py; the statistics of tests/test_backward_gpu.py): loss ratio, denoiser output and sampled
+    global gradient rel-L2.  The oracle package is imported HERE only, as the checker of an already-timed path."""
+    gold = ROOT / "tests" / "golden" / "train_kubric_32x48.pt"
+    if not gold.exists():
+        return None
+    from gcd_amd import autograd_ops as AO
+    from gcd_amd import training as TR
+    from gcd_amd.video_model import VideoUNet
+    from oracle import svd_unet_ref as O, weights
+    from oracle.make_golden_cfg4 import inputs
+    from oracle.make_golden_fullres import sample
+    G = torch.load(gold)
+    with torch.device("meta"):
+        net = VideoUNet(**O.KUBRIC.as_reference_kwargs())
+    sd = weights.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, G["salt"])
+    net = net.to_empty(device=dev)
+    net.load_state_dict(sd)
+    del sd
+    net.train()
+    x0, noise, cond, sig = inputs()
+    AO.set_train_dtype(dtype)
+    AO.PACK.clear()
+    try:
+        den = TR.TrainDenoiser({"target": "gcd_amd.denoiser_scaling.VScalingWithEDMcNoise"}, use_checkpoint=True)
+        loss_fn = TR.StandardDiffusionLoss(
+            sigma_sampler_config={"target": "gcd_amd.training.EDMSampling", "params": {"p_mean": 1.0, "p_std": 1.6}},
+            loss_weighting_config={"target": "gcd_amd.training.EDMWeighting", "params": {"sigma_data": 1.0}},
+            focus_top=0.1, focus_steps=5000, batch2model_keys=["image_only_indicator", "num_video_frames"])
+        sg = sig.to(dev)
+        out = den(net, (x0 + noise * sig[:, None, None, None]).to(dev), sg, {k: v.to(dev) for k, v in cond.items()},
+                  num_video_frames=G["T"], image_only_indicator=torch.zeros(G["B"], G["T"], device=dev))
+        wgt = loss_fn.loss_weighting(sg)[:, None, None, None]
+        loss = loss_fn.get_loss(out, x0.to(dev), wgt, {"global_step": G["step"]}).mean()
+        (loss * 1024.0).backward()
+        torch.cuda.synchronize(dev)
+    finally:
+        AO.set_train_dtype("fp16")
+        AO.PACK.clear()
+
+    def rel(a, b):
+        a, b = a.double(), b.double()
+        return float((a - b).norm() / b.norm().clamp_min(1e-30))
+    num = den_ = 0.0
+    total_ref = sum(v * v for v in G["grad_norms"].values()) ** 0.5
+    for name, prm in net.named_parameters():
+        if name in G["dead"] or G["grad_norms"][name] < 1e-7 * total_ref or prm.grad is None:
+            continue
+        ref_s = G["grad_samples"][name].double()
+        got_s = sample(prm.grad.detach().float().cpu() / 1024.0, 128).double()
+        num += float((got_s - ref_s).pow(2).sum())
+        den_ += float(ref_s.pow(2).sum())
+    res = {"fixture": "tests/golden/train_kubric_32x48.pt (unmodified reference, fp32 autograd, CPU)",
+           "loss_ratio_minus_1": float(loss) / G["loss"] - 1.0,
+           "output_rel_l2": rel(sample(out.detach().cpu(), 65536), G["out_samples"]),
+           "gradient_global_rel_l2": (num / den_) ** 0.5}
+    del net
+    torch.cuda.empty_cache()
+    return res
+
+
+def main_train(args):
+    """`python bench.py --train`: BASELINE.json cfg4 on one GPU — ONE JSON line, separate from the sampler line (whose
+    format the driver parses): the fine-tune step in bf16 (what cfg4 names) and fp16, at 2 clips (cfg4's per-GPU batch)."""
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    legs = {dt: train_leg(dev, dt, max(args.steps // 2, 3)) for dt in ("bf16", "fp16")}
+    parity = None
+    if not args.no_cpu_baseline:
+        parity = {dt: train_parity(dev, dt) for dt in ("bf16", "fp16")}
+    bars = ROOT / "tests" / "golden" / "autocast_bars.json"
+    ref_bf16 = None
+    if bars.exists():
+        ref_bf16 = json.loads(bars.read_text()).get("cfg4_reference_bf16_autocast_vs_own_fp32")
+        if ref_bf16:
+            ref_bf16 = {k: ref_bf16[k] for k in ("output_rel_l2", "gradient_global_rel_l2", "loss_ratio_minus_1")}
+    line = {"metric": "fine-tune steps/sec, SVD-UNet (loss_fn forward+backward+Adam), 2 clips x 14 frames of 32x48 latents, 1 MI355X",
+            "value": round(1.0 / legs["bf16"]["step_s"], 3), "unit": "steps/s", "n_gpus": 1, "higher_is_better": True,
+            "dtype": "bf16", "data": "synthetic", "vs_baseline": None,
+            "config": {"workload": "BASELINE.json configs[4] per-GPU shape (train_kubric_max90.yaml:209-234); single GPU: "
+                                   "no gradient exchange (tools/first_multi_gpu.sh runs the DDP form)"},
+            "train": legs, "parity_vs_reference_fp32_autograd": parity,
+            "reference_own_bf16_autocast_vs_its_fp32": ref_bf16,
+            "roofline": {"bound": "mfma", "achieved": legs["bf16"]["tflops"], "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": legs["bf16"]["frac_of_2p5_pflops"], "traffic": None}}
+    print(json.dumps(line))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,9 +442,14 @@ def main():
                          "contract), all of them feed timing_stats (median)")
     ap.add_argument("--dump-profile", type=str, default=None,
                     help="write the per-launch HIP-event table of the instrumented step (JSON)")
+    ap.add_argument("--train", action="store_true",
+                    help="instead of the sampler step: BASELINE.json cfg4's fine-tune step on one GPU, bf16 and fp16 "
+                         "operands, with its parity against the reference's fp32 autograd golden (one JSON line)")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.train:
+        return main_train(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # self-launch: one rank per GPU under torch.distributed.run (what the driver does itself)
         import socket
@@ -416,7 +614,7 @@ def main():
                          "launches_per_step": gk["launches"],
                          "algorithmic_tflop_per_step": round(gk["flops"] / 1e12, 3),
                          "kernel_ms_per_step": round(gk["ms"], 3)},
-            "attention": {"kernel": "attn_spatial64_kernel (72x128, 36x64 tokens) + attn_spatial_kernel", "achieved": round(
+            "attention": {"kernel": "attn_spatial64p_kernel (72x128, 36x64 tokens) + attn_spatial_kernel", "achieved": round(
                 ak["flops"] / (ak["ms"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
                 "algorithmic_tflop_per_step": round(ak["flops"] / 1e12, 3),
                 "kernel_ms_per_step": round(ak["ms"], 3), "launches_per_step": ak["launches"]},

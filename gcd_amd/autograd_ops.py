@@ -140,11 +140,32 @@ set_wgrad_impl(os.environ.get("GCD_TRAIN_WGRAD", "tr"))     # a typo in the vari
 # The planned engine (gcd_amd/train_plan.py) sets this to an object with `grad_dest(param) -> fp32 tensor of the parameter's
 # shape | None` and `accumulate`: weight gradients are then written by the kernel STRAIGHT into that tensor, in the
 # parameter's own layout (gcd_wgrad_tr_f16_ex) — no padded temporary, no permuted copy.  None on the autograd path.
-_GRAD_SINK = None
+# Round 6: not a module global any more.  The sink (and the fp16 pass-through switch below) live in a per-THREAD scope that a
+# plan opens around the operator calls of ITS OWN backward / forward (`grad_sink(plan)`, `f16_passthrough(True)`): two plans,
+# two host threads (one per GPU) or a DDP listener that re-enters the operators cannot see each other's setting.
+import contextlib as _contextlib
+import threading as _threading
+
+_SCOPE = _threading.local()
+
+
+def _sink():
+    return getattr(_SCOPE, "sink", None)
+
+
+@_contextlib.contextmanager
+def grad_sink(plan):
+    old = getattr(_SCOPE, "sink", None)
+    _SCOPE.sink = plan
+    try:
+        yield plan
+    finally:
+        _SCOPE.sink = old
 
 
 def _sink_dest(*params):
     """The flat-buffer destination of one parameter, or of several that lie back to back in it (q | k | v)."""
+    _GRAD_SINK = _sink()
     if _GRAD_SINK is None:
         return None
     ds = [_GRAD_SINK.grad_dest(p) for p in params]
@@ -173,7 +194,7 @@ def _wgrad(dy16: torch.Tensor, x16: torch.Tensor, dest: Optional[torch.Tensor] =
             scratch = torch.empty(int(lib.gcd_wgrad_tr_scratch_floats(M, N, K)), dtype=_f32, device=dy16.device)
             _lib.check_train(lib.gcd_wgrad_tr_f16_ex(
                 dy16.data_ptr(), dy16.stride(0), x16.data_ptr(), x16.stride(0), M, N, K, int(dy16.dtype == _bf16),
-                dest.data_ptr(), c_real, taps, n_real, c_real, int(bool(_GRAD_SINK is not None and _GRAD_SINK.accumulate)),
+                dest.data_ptr(), c_real, taps, n_real, c_real, int(bool(_sink() is not None and _sink().accumulate)),
                 scratch.data_ptr(), scratch.numel(), _stream()), "gcd_wgrad_tr_f16_ex")
             return dest
     dw = torch.empty(N, K, dtype=_f32, device=dy16.device)
@@ -202,7 +223,7 @@ def _wgrad_conv(dy16: torch.Tensor, x16: torch.Tensor, dest: torch.Tensor, conv:
     _lib.check_train(lib.gcd_wgrad_conv_tr_f16(
         dy16.data_ptr(), dy16.stride(0), x16.data_ptr(), x16.stride(0), M, N, Cp, conv, Ho, Wo, T, HW,
         int(dy16.dtype == _bf16), dest.data_ptr(), n_real, c_real,
-        int(bool(_GRAD_SINK is not None and _GRAD_SINK.accumulate)), scratch.data_ptr(), scratch.numel(), _stream()),
+        int(bool(_sink() is not None and _sink().accumulate)), scratch.data_ptr(), scratch.numel(), _stream()),
         "gcd_wgrad_conv_tr_f16")
     return dest
 
@@ -290,8 +311,8 @@ def _grad_contractions(dy32: torch.Tensor, x16: torch.Tensor, w_t16, need_dx: bo
 def _zeros(m: int, n: int, device) -> torch.Tensor:
     """A zeroed fp32 [m, n] accumulator: from the planned engine's per-step arena (one memset per step) when it runs,
     else a fresh torch.zeros (one fill launch each)."""
-    if _GRAD_SINK is not None:
-        z = _GRAD_SINK.zeros(m, n)
+    if _sink() is not None:
+        z = _sink().zeros(m, n)
         if z is not None:
             return z
     return torch.zeros(m, n, dtype=_f32, device=device)
@@ -628,7 +649,7 @@ def _gn_bwd(x, dy, stats, g32, b32, rows_per_inst, silu, dest=None, dx_add=None)
     if dest is not None and dest[0] is not None and dest[1] is not None:
         _lib.check_train(_lib.load_train().gcd_gn_affine_grads(
             AB.data_ptr(), ninst, Cc, dest[0].data_ptr(), dest[1].data_ptr(),
-            int(bool(_GRAD_SINK is not None and _GRAD_SINK.accumulate)), _stream()), "gcd_gn_affine_grads")
+            int(bool(_sink() is not None and _sink().accumulate)), _stream()), "gcd_gn_affine_grads")
         return dx, dest[0], dest[1]
     ab = AB.sum(0).float()
     return dx, ab[:, 1].contiguous(), ab[:, 0].contiguous()
@@ -690,7 +711,7 @@ class Fused(torch.autograd.Function):
                 a16, g32 = _ln_fwd(x, gamma, beta, norm[1], dt)
             else:
                 a16, stats, g32, b32 = _gn_fwd(x, gamma, beta, norm[1], norm[2], norm[3], dt)
-        elif _F16_PASSTHROUGH and getattr(x, "_gcd_f16", None) is not None and x._gcd_f16[1] == x._version and \
+        elif _f16_passthrough_on() and getattr(x, "_gcd_f16", None) is not None and x._gcd_f16[1] == x._version and \
                 x._gcd_f16[0].shape == x.shape:
             # x is the fp32 image of an fp16 tensor an attention core produced: that tensor IS the operand
             a16 = _as_dtype(x._gcd_f16[0], dt)
@@ -929,7 +950,25 @@ _LAST_F16 = [None]
 # Off by default: measured (same box, interleaved; profiles/r03b_train_ab.txt) the step is 5 ms SLOWER with it — the
 # forward's 16 attention outputs go through one cast less, but holding the fp16 tensors through the fp32 edge's
 # lifetime costs more than the casts save.
-_F16_PASSTHROUGH = os.environ.get("GCD_TRAIN_F16_PASSTHROUGH", "0") != "0"
+_F16_PASSTHROUGH_DEFAULT = os.environ.get("GCD_TRAIN_F16_PASSTHROUGH", "0") != "0"
+
+
+def _f16_passthrough_on() -> bool:
+    return getattr(_SCOPE, "f16_passthrough", _F16_PASSTHROUGH_DEFAULT)
+
+
+@_contextlib.contextmanager
+def f16_passthrough(on: bool = True):
+    """Scope (per thread) in which a Linear takes an input that already exists as the 16-bit operand without a cast."""
+    old = getattr(_SCOPE, "f16_passthrough", None)
+    _SCOPE.f16_passthrough = on
+    try:
+        yield
+    finally:
+        if old is None:
+            del _SCOPE.f16_passthrough
+        else:
+            _SCOPE.f16_passthrough = old
 
 
 def _with_f16(y: torch.Tensor) -> torch.Tensor:

@@ -37,9 +37,32 @@ from . import ops
 from .video_model import Downsample, SpatialVideoTransformer, Upsample, VideoResBlock, VideoUNet
 
 _f32 = torch.float32
-# callables fn(param) told the moment a parameter's gradient is final (training.GradBucketer registers its _on_grad here:
-# the planned engine assigns .grad itself, so torch's post-accumulate hooks never fire)
-GRAD_LISTENERS: List[Callable] = []
+# Gradient listeners: callables fn(param) told the moment a parameter's gradient is final (training.GradBucketer registers
+# its _on_grad: the planned engine assigns .grad itself, so torch's post-accumulate hooks never fire).  Round 6: they hang
+# on the PARAMETER (`param._gcd_grad_listeners`), not in a process-wide list — a second network, or a second bucketer on
+# other parameters, is never called for gradients that are not its own, and a listener dies with its parameters.
+def add_grad_listener(params, fn: Callable) -> None:
+    for p in params:
+        ls = p.__dict__.setdefault("_gcd_grad_listeners", [])
+        if fn not in ls:
+            ls.append(fn)
+
+
+def remove_grad_listener(params, fn: Callable) -> None:
+    for p in params:
+        ls = p.__dict__.get("_gcd_grad_listeners")
+        if ls and fn in ls:
+            ls.remove(fn)
+            if not ls:
+                del p.__dict__["_gcd_grad_listeners"]
+
+
+def _notify(plan, p) -> None:
+    if plan.on_param_grad is not None:
+        plan.on_param_grad(p)
+    if plan.listeners_enabled:
+        for fn in tuple(p.__dict__.get("_gcd_grad_listeners", ())):
+            fn(p)
 
 
 def _stream():
@@ -78,11 +101,10 @@ def _fused_fwd_from16(kind, x16, params, residual=None, rowvec=None):
     """A Linear whose input already exists as the 16-bit operand (an attention core's fp16 output): no fp32 image of it, no
     cast back (autograd_ops' fp16 pass-through, which the autograd engine measured slower because it holds the tensors)."""
     x16._gcd_f16 = (x16, x16._version)
-    old, A._F16_PASSTHROUGH = A._F16_PASSTHROUGH, True
     try:
-        return _fused_fwd(kind, x16, params, residual=residual, rowvec=rowvec)
+        with A.f16_passthrough(True):
+            return _fused_fwd(kind, x16, params, residual=residual, rowvec=rowvec)
     finally:
-        A._F16_PASSTHROUGH = old
         del x16._gcd_f16          # (the tag refers to the tensor itself: no reference cycle left behind)
 
 
@@ -101,11 +123,8 @@ def _fused_bwd(plan: "TrainPlan", ctx: _Ctx, dy: torch.Tensor, need_x: bool = Tr
     ctx.norm_dest = (plan.grad_dest(gm.weight), plan.grad_dest(gm.bias)) if want_norm else None
     bias = params[1] if len(params) == 2 else None
     ctx.bias_dest = plan.grad_dest(bias) if bias is not None and bias.requires_grad else None
-    A._GRAD_SINK = plan                    # weight gradients are written in place (autograd_ops._sink_dest)
-    try:
+    with A.grad_sink(plan):                # weight gradients are written in place (autograd_ops._sink_dest)
         out = A.Fused.backward(ctx, dy)
-    finally:
-        A._GRAD_SINK = None
     dx, d_vec, dgamma, dbeta = out[1], out[3], out[4], out[5]
     if dx_add is not None and not fused_add and dx is not None:
         dx = dx.add_(dx_add)
@@ -462,6 +481,7 @@ class TrainPlan:
         self.unet = unet
         self.set_checkpoint(use_checkpoint)
         self.on_param_grad = on_param_grad
+        self.listeners_enabled = True
         self.accumulate = False
         self.need_dx = False
         dev = next(unet.parameters()).device
@@ -582,10 +602,7 @@ class TrainPlan:
             return
         self._reached.add(id(p))
         p.grad = self._gview[id(p)]
-        if self.on_param_grad is not None:
-            self.on_param_grad(p)
-        for fn in GRAD_LISTENERS:
-            fn(p)
+        _notify(self, p)
 
     def grads_are_live(self) -> bool:
         """True when the parameters' .grad are this plan's views, i.e. a previous backward of the current accumulation
@@ -663,6 +680,14 @@ class TrainPlan:
         for owners, kind, tensor in self._pack_forms:
             key = (tuple(q.data_ptr() for q in owners), tuple(tuple(q.shape) for q in owners), kind)
             A.PACK._d[key] = (tuple(q._version for q in owners), tensor)
+        # the parameter versions these forms were made from: `forward` repacks when ANY optimizer (not only the in-repo
+        # fused Adam, which clears PACK) has stepped since — a stale form would otherwise be rebuilt per weight with torch ops
+        self._packed_versions = tuple(q._version for owners, _, _ in self._pack_forms for q in owners)
+
+    def _pack_is_stale(self) -> bool:
+        if self._pack_tables is None or not A.PACK._d or getattr(self, "_packed_versions", None) is None:
+            return True
+        return self._packed_versions != tuple(q._version for owners, _, _ in self._pack_forms for q in owners)
 
     def _build_pack_tables(self, fdt, gdt) -> None:
         dev = self.device
@@ -828,16 +853,18 @@ class TrainPlan:
         return x + vec.repeat_interleave(rows, dim=0)
 
     def rowblock_sum(self, x, rows):
-        A._GRAD_SINK = self
-        try:
+        with A.grad_sink(self):
             return A._colsum(x.contiguous(), rows)
-        finally:
-            A._GRAD_SINK = None
 
     # ---- forward ----
-    def forward(self, x, timesteps, context, y, num_video_frames: int, image_only_indicator):
+    def forward(self, x, timesteps, context, y, num_video_frames: int, image_only_indicator, record: bool = True):
+        """record=False (validation / image logging under torch.no_grad()): nothing is kept for a backward pass — no unit
+        contexts, no trace.  The plan holds ONE forward's state: a backward of an EARLIER forward raises (see `_serial`)."""
         unet = self.unet
         ops._need_gpu(x, timesteps, context, y)
+        # every forward gets a serial number; `_PlannedUNet.backward` refuses to run for any but the LATEST forward (its
+        # activations are the only ones the plan still holds) instead of silently differentiating the wrong ones
+        self._serial = getattr(self, "_serial", 0) + 1
         T = num_video_frames
         N, _, H, W = x.shape
         assert N % T == 0 and context.dim() == 3
@@ -848,7 +875,7 @@ class TrainPlan:
             self._decide_checkpoint(N * H * W)
         self.ioi = image_only_indicator.to(x.device)
         self._make_alphas()
-        if self._pack_tables is None or self._pack_dtypes != (A._dt(A.FWD_DTYPE), A._dt(A.GRAD_DTYPE)) or not A.PACK._d:
+        if self._pack_dtypes != (A._dt(A.FWD_DTYPE), A._dt(A.GRAD_DTYPE)) or self._pack_is_stale():
             self.repack()
         self._reached = set()
         self._arena.zero_()
@@ -856,7 +883,7 @@ class TrainPlan:
         self._small_forward(timesteps, context, y)
         n_bl = len(self.res_blocks) + len(self.transformers)
         self._dalpha = zeros_or_new(self, n_bl, N)
-        save = not self.use_checkpoint
+        save = record and not self.use_checkpoint
         h = x.float().permute(0, 2, 3, 1).reshape(N * H * W, -1).contiguous()
         trace = []          # (unit, input, H, W, saved | None)
         hs: List[torch.Tensor] = []
@@ -866,7 +893,8 @@ class TrainPlan:
             for u in units:
                 hin = h
                 h, sv = u.fwd(hin, st[0], st[1], save)
-                trace.append((u, hin if self.use_checkpoint else None, st[0], st[1], sv))
+                if record:
+                    trace.append((u, hin if self.use_checkpoint else None, st[0], st[1], sv))
                 if isinstance(u, _ConvUnit):
                     st[0], st[1] = u.out_hw(st[0], st[1])
             return h
@@ -880,7 +908,7 @@ class TrainPlan:
             trace.append(("cat", h.shape[1], skip.shape[1]))
             h = run(units, torch.cat([h, skip], dim=1))
         h = run([self._units["head"]], h)
-        self._trace = trace
+        self._trace = trace if record else None
         out = h.reshape(N, H, W, -1).permute(0, 3, 1, 2).contiguous()
         return out
 
@@ -1108,13 +1136,13 @@ class GraphedPlan:
             st["d_out"] = d_out.detach().float().contiguous().clone()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            listeners, GRAD_LISTENERS[:] = list(GRAD_LISTENERS), []       # host callbacks must not run inside a capture
-            cb, plan.on_param_grad = plan.on_param_grad, None
+            cb, plan.on_param_grad = plan.on_param_grad, None       # host callbacks must not run inside a capture
+            plan.listeners_enabled = False
             try:
                 with torch.cuda.graph(g, pool=self.pool):
                     plan.backward(st["d_out"], accumulate=False)
             finally:
-                GRAD_LISTENERS[:] = listeners
+                plan.listeners_enabled = True
                 plan.on_param_grad = cb
             self.g_bwd = g
             self.reached = [p for p in plan.unet.parameters() if id(p) in plan._reached]
@@ -1122,10 +1150,7 @@ class GraphedPlan:
         self.g_bwd.replay()
         for p in self.reached:
             p.grad = plan._gview[id(p)]
-            if plan.on_param_grad is not None:
-                plan.on_param_grad(p)
-            for fn in GRAD_LISTENERS:
-                fn(p)
+            _notify(plan, p)
         self.mode = "graph"
         return None
 
@@ -1139,12 +1164,19 @@ class _PlannedUNet(torch.autograd.Function):
         ctx.plan = plan
         ctx.graphed = USE_GRAPH and plan.graphed is not None
         if ctx.graphed:
-            return plan.graphed.forward(x, timesteps, context, y, T, ioi)
-        return plan.forward(x, timesteps, context, y, T, ioi)
+            out = plan.graphed.forward(x, timesteps, context, y, T, ioi)
+        else:
+            out = plan.forward(x, timesteps, context, y, T, ioi)
+        ctx.serial = getattr(plan, "_serial", 0)
+        return out
 
     @staticmethod
     def backward(ctx, d_out):
         plan = ctx.plan
+        if ctx.serial != getattr(plan, "_serial", 0):
+            raise RuntimeError("gcd_amd planned training pass: backward of a forward that is no longer the network's latest "
+                               "(another forward — e.g. a validation pass — ran in between and replaced the activations "
+                               "the plan keeps); run the extra forward after backward")
         if ctx.graphed:
             plan.graphed.backward(d_out)
         else:
@@ -1181,7 +1213,19 @@ def plan_for(unet: VideoUNet, use_checkpoint: Optional[bool] = None) -> TrainPla
 def unet_forward_planned(unet: VideoUNet, x, timesteps, context, y, num_video_frames: int, image_only_indicator,
                          use_checkpoint: Optional[bool] = None) -> torch.Tensor:
     """Drop-in for `training.unet_forward_train`: same arguments, same result, one autograd node."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, context, y)):
+        # The planned pass computes PARAMETER gradients only (its few-row Linears treat their inputs as data).  A
+        # conditioner trained through `vector` / `crossattn` (the kubric configs train SphericalEmbedder.proj,
+        # encoders/modules.py) or a gradient with respect to x needs the operator-level autograd engine: use it, loudly once.
+        from . import training as _TR
+        if not getattr(unet_forward_planned, "_warned", False):
+            import warnings
+            warnings.warn("gcd_amd: an input of the UNet requires grad; this step runs on the operator-level autograd engine "
+                          "(training.unet_forward_train), not the planned pass", RuntimeWarning)
+            unet_forward_planned._warned = True
+        return _TR.unet_forward_train(unet, x, timesteps, context, y, num_video_frames, image_only_indicator,
+                                      use_checkpoint=use_checkpoint)
     plan = plan_for(unet, use_checkpoint)
     if not torch.is_grad_enabled():
-        return plan.forward(x, timesteps, context, y, num_video_frames, image_only_indicator)
+        return plan.forward(x, timesteps, context, y, num_video_frames, image_only_indicator, record=False)
     return _PlannedUNet.apply(plan, plan._anchor, x, timesteps, context, y, num_video_frames, image_only_indicator)

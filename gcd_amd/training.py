@@ -263,10 +263,13 @@ class TrainDenoiser(nn.Module):
     """Denoiser.forward (denoiser.py:23-49) over OpenAIWrapper.forward (wrappers.py:23-34) with the
     training-mode UNet underneath: `denoiser(network, input, sigma, cond, **kwargs)`."""
 
-    def __init__(self, scaling_config: Dict, use_checkpoint: Optional[bool] = None):
+    def __init__(self, scaling_config: Dict, use_checkpoint: Optional[bool] = None, engine: Optional[str] = None):
         super().__init__()
         self.scaling = instantiate_from_config(scaling_config)
         self.use_checkpoint = use_checkpoint        # None: follow the network's `use_checkpoint`
+        if engine not in (None, "planned", "autograd"):
+            raise ValueError(f"train engine must be 'planned' or 'autograd', got {engine!r}")
+        self.engine = engine                        # None: the process default (set_train_engine / GCD_TRAIN_ENGINE)
 
     def forward(self, network, input, sigma, cond, **additional_model_inputs):
         unet = getattr(network, "diffusion_model", network)
@@ -277,7 +280,7 @@ class TrainDenoiser(nn.Module):
         concat = cond.get("concat")
         if concat is not None and concat.numel() > 0:
             x = torch.cat((x, concat.type_as(x)), dim=1)
-        if TRAIN_ENGINE == "planned":
+        if (self.engine or TRAIN_ENGINE) == "planned":
             from .train_plan import unet_forward_planned as run
         else:
             run = unet_forward_train
@@ -540,8 +543,8 @@ class GradBucketer:
             # the planned engine (train_plan.py) writes .grad itself, so torch's hooks never fire for its parameters: it
             # calls the listeners below the moment a parameter's gradient is final
             from . import train_plan
-            self._listener = lambda p: self._on_grad(p) if id(p) in self._bucket_of else None
-            train_plan.GRAD_LISTENERS.append(self._listener)
+            self._listener = self._on_grad
+            train_plan.add_grad_listener(self.params, self._listener)
 
     def _reset_ready(self) -> None:
         for i, b in enumerate(self.buckets):
@@ -642,8 +645,7 @@ class GradBucketer:
         self._hooks = []
         if getattr(self, "_listener", None) is not None:
             from . import train_plan
-            if self._listener in train_plan.GRAD_LISTENERS:
-                train_plan.GRAD_LISTENERS.remove(self._listener)
+            train_plan.remove_grad_listener(self.params, self._listener)
             self._listener = None
 
 

@@ -43,12 +43,11 @@ def tiny(gpu):
     return _build(E.TINY, gpu)
 
 
-@pytest.mark.parametrize("impl", [0, 1, 2], ids=["auto", "general", "pingpong"])
-@pytest.mark.parametrize("frames,C,H,W", [(2, 64, 8, 12), (3, 320, 32, 32), (1, 32, 6, 10)])
+# (the general kernel walks K in 64-channel chunks: the 32-channel case is not one of its cases)
+@pytest.mark.parametrize("impl,frames,C,H,W", [(i, *c) for i in (0, 1, 2) for c in ((2, 64, 8, 12), (3, 320, 32, 32), (1, 32, 6, 10))
+                                               if not (i == 1 and c[1] % 64)])
 def test_conv3x3_stride2_asymmetric_padding(gpu, impl, frames, C, H, W):
     from gcd_amd import ops, packing
-    if impl == 1 and C % 64:
-        pytest.skip("the general kernel walks K in 64-channel chunks")
     ops.tune_set(ops.TUNE_GEMM_IMPL, impl)
     try:
         g = torch.Generator().manual_seed(C + H)

@@ -411,3 +411,87 @@ def test_conv_weight_gradients_without_im2col(gpu, bf16):
         o0, o1 = run(dyt.to(dt).to(gpu).contiguous(), xt.to(dt).to(gpu).contiguous(), Cout, Cc, 2, Cout, Cc, T=T, HW=HW)
         assert rel_l2(o0, ref) < 2e-4, (clips, T, HW, rel_l2(o0, ref))
         assert rel_l2(o1, 2 * ref) < 2e-4
+
+
+def _tiny_step_inputs(gpu, seed, T=4, H=16, W=16):
+    cfg = O.TINY
+    g = torch.Generator().manual_seed(seed)
+    return dict(x=torch.randn(2 * T, 8, H, W, generator=g).to(gpu), ts=torch.linspace(-1.0, 1.5, 2 * T).to(gpu),
+                ctx=torch.randn(2 * T, 1, cfg.context_dim, generator=g).to(gpu),
+                y=torch.randn(2 * T, cfg.adm_in_channels + cfg.aux_emb_dim, generator=g).clamp(-1, 1).to(gpu),
+                tgt=torch.randn(2 * T, 4, H, W, generator=g).to(gpu), ioi=torch.zeros(2, T, device=gpu), T=T)
+
+
+def test_two_plans_alternating_in_one_process_do_not_interfere(gpu):
+    """Round 6 (no process-global state in the training engines): two networks, each with its own TrainPlan, stepped
+    ALTERNATELY in one process — forward A, forward B, backward A, backward B, with a gradient listener on A only — give,
+    bit for bit, the gradients each gives when it runs alone; the listener hears A's parameters and none of B's."""
+    from gcd_amd import autograd_ops as A, train_plan as TP
+    from gcd_amd.train_plan import unet_forward_planned
+    na, nb = _tiny(gpu, salt=5), _tiny(gpu, salt=6)
+    ia, ib = _tiny_step_inputs(gpu, 41), _tiny_step_inputs(gpu, 42)
+
+    def alone(net, s):
+        for p in net.parameters():
+            p.grad = None
+        out = unet_forward_planned(net, s["x"], s["ts"], s["ctx"], s["y"], s["T"], s["ioi"], use_checkpoint=False)
+        ((out - s["tgt"]) ** 2).mean().mul(64.0).backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    oa, ga = alone(na, ia)
+    ob, gb = alone(nb, ib)
+    heard = []
+    TP.add_grad_listener(list(na.parameters()), heard.append)
+    try:
+        for net in (na, nb):
+            for p in net.parameters():
+                p.grad = None
+        out_a = unet_forward_planned(na, ia["x"], ia["ts"], ia["ctx"], ia["y"], ia["T"], ia["ioi"], use_checkpoint=False)
+        out_b = unet_forward_planned(nb, ib["x"], ib["ts"], ib["ctx"], ib["y"], ib["T"], ib["ioi"], use_checkpoint=False)
+        ((out_a - ia["tgt"]) ** 2).mean().mul(64.0).backward()
+        ((out_b - ib["tgt"]) ** 2).mean().mul(64.0).backward()
+        torch.cuda.synchronize()
+    finally:
+        TP.remove_grad_listener(list(na.parameters()), heard.append)
+    assert torch.equal(out_a, oa) and torch.equal(out_b, ob)
+    for net, ref in ((na, ga), (nb, gb)):
+        for n, p in net.named_parameters():
+            if n in ref:
+                assert torch.equal(p.grad, ref[n]), n
+    ids_a, ids_b = {id(p) for p in na.parameters()}, {id(p) for p in nb.parameters()}
+    assert heard and all(id(p) in ids_a for p in heard) and not any(id(p) in ids_b for p in heard)
+    assert A._sink() is None
+
+
+def test_planned_engine_inputs_that_need_gradients_and_no_grad_forwards(gpu):
+    """Round-5 review: (1) the planned pass computes parameter gradients only — an input that requires grad (a conditioner
+    trained through `vector`, as the kubric configs train SphericalEmbedder.proj) must not silently get none: the call runs
+    on the operator-level engine and y.grad equals that engine's; (2) a forward under torch.no_grad() keeps nothing for a
+    backward pass; (3) a backward of a forward that is no longer the latest raises instead of using the wrong activations."""
+    import warnings
+    from gcd_amd import training as TR
+    from gcd_amd.train_plan import plan_for, unet_forward_planned
+    net = _tiny(gpu, salt=5)
+    s = _tiny_step_inputs(gpu, 43)
+    grads = {}
+    for name, fn in (("planned-entry", unet_forward_planned), ("autograd", TR.unet_forward_train)):
+        y = s["y"].clone().requires_grad_()
+        for p in net.parameters():
+            p.grad = None
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            out = fn(net, s["x"], s["ts"], s["ctx"], y, s["T"], s["ioi"], use_checkpoint=True)
+        ((out - s["tgt"]) ** 2).mean().mul(64.0).backward()
+        torch.cuda.synchronize()
+        assert y.grad is not None and float(y.grad.abs().max()) > 0
+        grads[name] = y.grad.clone()
+    assert torch.equal(grads["planned-entry"], grads["autograd"])
+    plan = plan_for(net, True)
+    with torch.no_grad():
+        o1 = unet_forward_planned(net, s["x"], s["ts"], s["ctx"], s["y"], s["T"], s["ioi"], use_checkpoint=True)
+    assert plan._trace is None and not o1.requires_grad
+    out = unet_forward_planned(net, s["x"], s["ts"], s["ctx"], s["y"], s["T"], s["ioi"], use_checkpoint=True)
+    with torch.no_grad():
+        unet_forward_planned(net, s["x"], s["ts"], s["ctx"], s["y"], s["T"], s["ioi"], use_checkpoint=True)
+    with pytest.raises(RuntimeError, match="no longer the network's latest"):
+        ((out - s["tgt"]) ** 2).mean().backward()

@@ -368,11 +368,31 @@ def test_train_engine_switch_and_planned_engine_refuse_loudly():
     with pytest.raises(_lib.GcdError, match="GPU"):
         TP.TrainPlan(net)
     # a bucketer that is not active (single process) registers nothing; close() is idempotent
-    n0 = len(TP.GRAD_LISTENERS)
     b = TR.GradBucketer(net.parameters(), None)
-    assert len(TP.GRAD_LISTENERS) == n0
+    assert not any("_gcd_grad_listeners" in p.__dict__ for p in net.parameters())
     b.close()
     b.close()
+    # listeners hang on the parameters they are for (round 6: no process-wide list); removing the last one removes the slot
+    ps = list(net.parameters())[:3]
+    seen = []
+    TP.add_grad_listener(ps, seen.append)
+    TP.add_grad_listener(ps[:1], seen.append)              # registering twice does not call twice
+    assert all(p.__dict__["_gcd_grad_listeners"] == [seen.append] for p in ps)
+    TP.remove_grad_listener(ps, seen.append)
+    assert not any("_gcd_grad_listeners" in p.__dict__ for p in net.parameters())
+    with pytest.raises(ValueError):
+        TR.TrainDenoiser({"target": "gcd_amd.denoiser_scaling.VScalingWithEDMcNoise"}, engine="planed")
+    # the in-place gradient sink and the fp16 pass-through are per-thread scopes, restored on exit
+    assert A._sink() is None
+    with A.grad_sink("plan-a"):
+        with A.grad_sink("plan-b"):
+            assert A._sink() == "plan-b"
+        assert A._sink() == "plan-a"
+    assert A._sink() is None
+    d = A._f16_passthrough_on()
+    with A.f16_passthrough(not d):
+        assert A._f16_passthrough_on() == (not d)
+    assert A._f16_passthrough_on() == d
 
 
 def test_checkpoint_policy_is_a_memory_decision():
