@@ -386,7 +386,7 @@ def train_parity(dev, dtype: str):
         num += float((got_s - ref_s).pow(2).sum())
         den_ += float(ref_s.pow(2).sum())
     res = {"fixture": "tests/golden/train_kubric_32x48.pt (unmodified reference, fp32 autograd, CPU)",
-           "loss_ratio_minus_1": float(loss) / G["loss"] - 1.0,
+           "loss_ratio_minus_1": float(loss.detach()) / G["loss"] - 1.0,
            "output_rel_l2": rel(sample(out.detach().cpu(), 65536), G["out_samples"]),
            "gradient_global_rel_l2": (num / den_) ** 0.5}
     del net

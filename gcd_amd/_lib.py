@@ -58,6 +58,8 @@ class FfDesc(C.Structure):
         ("out", C.c_void_p), ("ldo", C.c_int64), ("out_kind", C.c_int32),
         ("frame_alpha", C.c_void_p), ("rows_per_alpha", C.c_int32), ("s_acc", C.c_float), ("s_r2", C.c_float),
         ("M", C.c_int32), ("C", C.c_int32), ("hidden", C.c_int32), ("sched", C.c_int32),
+        ("x32", C.c_void_p), ("ldx32", C.c_int64), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p),
+        ("ln_eps", C.c_float), ("addvec", C.c_void_p), ("ld_addvec", C.c_int64), ("rows_per_vec", C.c_int32),
     ]
 
 
@@ -74,7 +76,7 @@ SIGNATURES = {
     "gcd_gemm_colstats_supported": (_i, [C.POINTER(GemmDesc)]),
     "gcd_gemm_hidden_blocked_supported": (_i, [_i, _i, _i]),
     "gcd_ff_packed_bytes": (_i64, []),
-    "gcd_ff_pack_f16": (_i, [_vp, _vp, _vp, _vp]),
+    "gcd_ff_pack_f16": (_i, [_vp, _vp, _vp, _i, _vp]),
     "gcd_ff_fused_supported": (_i, [_i, _i, _i]),
     "gcd_ff_fused_f16": (_i, [C.POINTER(FfDesc), _vp]),
     "gcd_groupnorm_stats_from_colsums": (_i, [_vp, _i, _vp, _i, _i64, _i64, _f, _vp, _vp]),

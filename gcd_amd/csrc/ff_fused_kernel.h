@@ -41,8 +41,20 @@ __device__ __forceinline__ void ff_static_for(F&& f) {
 }
 
 struct FfK {
-  const f16* X;        // [M][320] fp16 (LayerNorm output), leading dimension ldx
+  const f16* X;        // [M][320] fp16 (LayerNorm output), leading dimension ldx — the LN = false kernels
   int64_t ldx;
+  // the LN = true kernels (FeedForward WITH the LayerNorm in front of it, attention.py:566-572 / video_attention.py:109-140:
+  // x = ff(norm(x)) + x): z = x32 [+ addvec[m / rows_per_vec]] is read ONCE, in the accumulator layout, and serves as the
+  // residual (it initialises the accumulators: R1 is not read) AND, normalised over its 320 channels and rounded to fp16, as
+  // GEMM1's operand — neither the LayerNorm kernel's 330 MB read + 165 MB write nor this kernel's 165 MB read of them happen
+  const float* x32;
+  int64_t ldx32;
+  const float* ln_gamma;
+  const float* ln_beta;
+  float ln_eps;
+  const float* addvec;     // optional per-row-block vector (the frame position embedding of video_attention.py:283-284)
+  int64_t ld_addvec;
+  int rows_per_vec;
   const f16* Wp;       // ff_pack_kernel output: [41][60][64][8] fp16 (chunk 40 = a copy of chunk 39: never consumed)
   const float* b1;     // [2560] fp32 in pack_geglu order (16 value / 16 gate)
   const float* b2;     // [320]
@@ -66,7 +78,7 @@ struct FfK {
 constexpr int FF_C = 320, FF_HID = 1280, FF_NCH = 40;
 constexpr int FF_W1_BYTES = 40960, FF_W2_BYTES = 20480, FF_CHUNK_BYTES = FF_W1_BYTES + FF_W2_BYTES;
 constexpr int FF_OFF_W1 = 0, FF_OFF_W2 = 2 * FF_W1_BYTES, FF_OFF_B1 = FF_OFF_W2 + 2 * FF_W2_BYTES;
-constexpr int FF_OFF_B2 = FF_OFF_B1 + 2560 * 4, FF_SMEM = FF_OFF_B2 + 320 * 4;     // 134 400 B
+constexpr int FF_OFF_B2 = FF_OFF_B1 + 2560 * 4, FF_OFF_LN = FF_OFF_B2 + 320 * 4, FF_SMEM = FF_OFF_LN + 2 * 320 * 4;     // 136 960 B
 
 // Probe knobs (tools/ff_fused_probe builds one binary per setting).  FF_ABL bits give WRONG results by design: 1 no LDS-DMA
 // in the loop, 2 no GELU operations, 4 no vmcnt / barrier in the loop, 8 no GEMM1 MFMAs, 16 no GEMM2 MFMAs, 32 no epilogue
@@ -103,6 +115,13 @@ constexpr int FF_OFF_B2 = FF_OFF_B1 + 2560 * 4, FF_SMEM = FF_OFF_B2 + 320 * 4;  
 #endif
 #ifdef FF_TIMING
 #define FF_STAMP(idx) do { if (blockIdx.x == 0 && t == 0 && p.dbg) p.dbg[(tile0 / gridDim.x) * 64 + (idx)] = __builtin_readcyclecounter(); } while (0)
+#elif defined(FF_STAMP_MODE) && FF_STAMP_MODE >= 10
+// (bisecting: real stamps for a subset of the indices)
+#define FF_STAMP(idx) do { if (((FF_STAMP_MODE == 10 && (idx) == 0) || (FF_STAMP_MODE == 11 && (idx) == 1) || (FF_STAMP_MODE == 12 && (idx) >= 2 && (idx) <= 4) || (FF_STAMP_MODE == 13 && (idx) == 5) || (FF_STAMP_MODE == 14 && (idx) >= 10)) && blockIdx.x == 0 && t == 0 && p.dbg) p.dbg[(tile0 / gridDim.x) * 64 + (idx)] = __builtin_readcyclecounter(); } while (0)
+#elif defined(FF_STAMP_MODE) && FF_STAMP_MODE == 1
+#define FF_STAMP(idx) asm volatile("; stamp" ::: "memory")
+#elif defined(FF_STAMP_MODE) && FF_STAMP_MODE == 2
+#define FF_STAMP(idx) do { if (blockIdx.x == 0 && t == 0 && p.dbg) asm volatile("s_nop 0"); } while (0)
 #else
 #define FF_STAMP(idx) do {} while (0)
 #endif
@@ -127,6 +146,22 @@ struct FfGelu<15> {
                                  2.314932873e-02f, -1.554679539e-02f, 1.299527435e-02f, -5.433510091e-03f};
 };
 
+// sum over the four lanes of a token's row (lane bits 4 and 5), result in all of them: two VALU cross-lane swaps
+// (v_permlane16_swap, v_permlane32_swap) — no trip through the LDS crossbar
+__device__ __forceinline__ float ff_sum_lane_bits_45(float a) {
+  {
+    const unsigned u = __float_as_uint(a);
+    const auto sw = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    a = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+  {
+    const unsigned u = __float_as_uint(a);
+    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    a = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+  return a;
+}
+
 // 16 bytes of the residual straight into the accumulator file; hipcc does not count an asm load (the caller's vmcnt(0) does)
 template <int OFF>
 __device__ __forceinline__ void ff_load_acc(f32x4& dst, const float* src) {
@@ -134,7 +169,9 @@ __device__ __forceinline__ void ff_load_acc(f32x4& dst, const float* src) {
 }
 
 // EPI: 0 = out = sa (acc + b2 + R1), fp32; 1 = ... + sr2 R2 (AlphaBlender), fp32; 2 = the same with an fp16 result
-template <int T, int DEG, int EPI>
+// LN: the LayerNorm in front of the FeedForward is computed here (FfK.x32 ...); the weights then come from ff_pack_kernel
+// with kperm = 1 (GEMM1's K order follows the accumulator layout's channel strips)
+template <int T, int DEG, int EPI, bool LN = false>
 __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
@@ -148,6 +185,11 @@ __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
 
   for (int i = t; i < 640; i += 256) ((f32x4*)(smem + FF_OFF_B1))[i] = ((const f32x4*)p.b1)[i];
   if (t < 80) ((f32x4*)(smem + FF_OFF_B2))[t] = ((const f32x4*)p.b2)[t];
+  if constexpr (LN) {
+    if (t >= 128 && t < 208) ((f32x4*)(smem + FF_OFF_LN))[t - 128] = ((const f32x4*)p.ln_gamma)[t - 128];
+    if (t >= 64 && t < 128) ((f32x4*)(smem + FF_OFF_LN + 1280))[t - 64] = ((const f32x4*)p.ln_beta)[t - 64];
+    if (t < 16) ((f32x4*)(smem + FF_OFF_LN + 1280))[64 + t] = ((const f32x4*)p.ln_beta)[64 + t];
+  }
   __syncthreads();
 
   const __amdgpu_buffer_rsrc_t rsrcW =
@@ -158,8 +200,13 @@ __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
   // does hipcc's own count for the loads it tracks across them)
   const __amdgpu_buffer_rsrc_t rsrcO = __builtin_amdgcn_make_buffer_rsrc(
       p.out, 0, (int)((int64_t)p.M * p.ldo * (OUT16 ? 2 : 4)), 0x00020000);
-  auto dma = [&](int goff, int lds_off) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (GCD_AS3 void*)(smem + lds_off), 16, (int)lane16, goff, 0, 0);
+  // piece n of a run of pieces that lie 1 KB apart in memory AND in LDS: pieces 4 q .. 4 q + 3 share one scalar offset pair
+  // and differ in the instruction's 12-bit offset, which the hardware adds to both addresses — a quarter of the scalar
+  // registers (the first build kept one SGPR pair per piece: the kernel sat at the SGPR limit)
+  auto dma = [&](int goff, int lds_off, auto Nn) {
+    constexpr int n = decltype(Nn)::value;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (GCD_AS3 void*)(smem + lds_off + (n >> 2) * 4096), 16, (int)lane16,
+                                             goff + (n >> 2) * 4096, (n & 3) * 1024, 0);
   };
   // slot s of an iteration -> fragment of the chunk: S1 / S2 alternate value and gate row blocks (rb = 2 (s / 20) + (s & 1),
   // k-step (s % 20) / 2), S3 walks the 20 channel blocks of W2
@@ -185,9 +232,8 @@ __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
   int par = 0;
   if ((int)blockIdx.x < ntiles) {
     // ---- first tile of this workgroup: W1(0) -> buffer 0, X fragments ----
-#pragma unroll
-    for (int n = 0; n < 10; ++n) dma((wave * 10 + n) * 1024, FF_OFF_W1 + (wave * 10 + n) * 1024);
-    load_x(X, tile_of(blockIdx.x) * TILE + wave * (16 * T));
+    ff_static_for<0, 10>([&](auto Nn) { dma(wave * 10240, FF_OFF_W1 + wave * 10240, Nn); });
+    if constexpr (!LN) load_x(X, tile_of(blockIdx.x) * TILE + wave * (16 * T));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
@@ -201,7 +247,7 @@ __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
       asm volatile("" : "+v"(X[tb][0]), "+v"(X[tb][1]), "+v"(X[tb][2]), "+v"(X[tb][3]), "+v"(X[tb][4]), "+v"(X[tb][5]),
                    "+v"(X[tb][6]), "+v"(X[tb][7]), "+v"(X[tb][8]), "+v"(X[tb][9]));
   };
-  pin_x();
+  if constexpr (!LN) pin_x();
 
   for (int tile0 = blockIdx.x; tile0 < ntiles; tile0 += gridDim.x) {
     const int m_base = tile_of(tile0) * TILE + wave * (16 * T);
@@ -209,6 +255,71 @@ __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
     const int m_next = has_next ? tile_of(tile0 + gridDim.x) * TILE + wave * (16 * T) : m_base;
     FF_STAMP(0);
     f32x4 out[20][T];
+    if constexpr (LN) {
+      // z = x32 [+ addvec] in the ACCUMULATOR layout (lane (r, g): token r, channels 16 cb + 4 g .. + 3 of every block cb):
+      // the residual the accumulators start from and, normalised (two-pass statistics over the 320 channels of a token =
+      // the 80 values of a lane + the lanes r + 16, r + 32, r + 48; the formula of norm.hip's layernorm16_kernel) and rounded
+      // to fp16, GEMM1's B fragments — the packer's K order (kperm) makes k-step ks of a lane exactly blocks 2 ks, 2 ks + 1.
+      f32x4 z[T][20];
+#pragma unroll
+      for (int tb = 0; tb < T; ++tb) {
+        const float* src = p.x32 + (int64_t)min(m_base + 16 * tb + r, p.M - 1) * p.ldx32 + 4 * g;
+#pragma unroll
+        for (int cb = 0; cb < 20; ++cb) z[tb][cb] = *(const f32x4*)(src + 16 * cb);
+      }
+      if (p.addvec) {
+        const float* av = p.addvec + (int64_t)(min(m_base, p.M - 1) / p.rows_per_vec) * p.ld_addvec + 4 * g;
+#pragma unroll
+        for (int cb = 0; cb < 20; ++cb) {
+          const f32x4 a = *(const f32x4*)(av + 16 * cb);
+#pragma unroll
+          for (int tb = 0; tb < T; ++tb) z[tb][cb] += a;
+        }
+      }
+#pragma unroll
+      for (int tb = 0; tb < T; ++tb) {
+        float sm = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < 20; ++cb) sm += (z[tb][cb][0] + z[tb][cb][1]) + (z[tb][cb][2] + z[tb][cb][3]);
+        const float mean = ff_sum_lane_bits_45(sm) * (1.0f / 320.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < 20; ++cb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = z[tb][cb][e] - mean;
+            q = fmaf(d, d, q);
+          }
+        const float rstd = rsqrtf(ff_sum_lane_bits_45(q) * (1.0f / 320.0f) + p.ln_eps);
+#pragma unroll
+        for (int cb = 0; cb < 20; ++cb) {
+          const f32x4 ga = *(const f32x4*)(smem + FF_OFF_LN + (16 * cb + 4 * g) * 4);
+          const f32x4 be = *(const f32x4*)(smem + FF_OFF_LN + 1280 + (16 * cb + 4 * g) * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) X[tb][cb >> 1][4 * (cb & 1) + e] = (f16)((z[tb][cb][e] - mean) * rstd * ga[e] + be[e]);
+          out[cb][tb] = z[tb][cb];
+          asm volatile("" : "+a"(out[cb][tb]));
+        }
+      }
+      pin_x();      // (made by VALU conversions: behind the pin before the first MFMA reads them)
+#if defined(FF_DEBUGX) && FF_DEBUGX == 1
+      if (p.dbg && tile0 == (int)blockIdx.x) {      // probe: this workgroup's first tile's operand fragments and statistics
+        f16x8* d = (f16x8*)p.dbg + ((size_t)blockIdx.x * 256 + t) * (T * 10);
+#pragma unroll
+        for (int tb = 0; tb < T; ++tb)
+#pragma unroll
+          for (int ks = 0; ks < 10; ++ks) d[tb * 10 + ks] = X[tb][ks];
+      }
+#endif
+#if defined(FF_LNFIX) && FF_LNFIX == 1
+      __builtin_amdgcn_sched_barrier(0);
+#elif defined(FF_LNFIX) && FF_LNFIX == 2
+      asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#elif defined(FF_LNFIX) && FF_LNFIX == 3
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#endif
+    }
     f32x4 aG[4][T];
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
@@ -223,11 +334,13 @@ __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
     float e_va[8 * T], e_g[8 * T], e_xc[8 * T], e_u[8 * T], e_p[8 * T];
 #pragma unroll
     for (int k = 0; k < 8 * T; ++k) e_va[k] = e_g[k] = e_xc[k] = e_u[k] = e_p[k] = 0.f;
-    const float* r1src[T];
+    const float* r1src[T] = {};
+    if constexpr (!LN) {
 #pragma unroll
-    for (int tb = 0; tb < T; ++tb)
-      r1src[tb] = (FF_ABL & 256) ? p.R1 + (int64_t)min(m_base + 16 * tb, p.M - 16) * p.ldr1 + lane * 4
-                                 : p.R1 + (int64_t)min(m_base + 16 * tb + r, p.M - 1) * p.ldr1 + 4 * g;
+      for (int tb = 0; tb < T; ++tb)
+        r1src[tb] = (FF_ABL & 256) ? p.R1 + (int64_t)min(m_base + 16 * tb, p.M - 16) * p.ldr1 + lane * 4
+                                   : p.R1 + (int64_t)min(m_base + 16 * tb + r, p.M - 1) * p.ldr1 + 4 * g;
+    }
 
     // ---- the GELU of a chunk as single VALU operations placed one by one behind the MFMAs ----
     // Element k (0 .. 8T-1): hidden half k / (4T), token block (k >> 2) % T, accumulator register k & 3.  Elements are
@@ -250,10 +363,14 @@ __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
         constexpr int pair = k / (4 * T), tb = (k >> 2) % T, e = k & 3;
         float res;
         if constexpr (st == 0) {
-          // the pin keeps the first read of the MFMA results behind the MFMAs issued so far (volatile asm statements keep
-          // their order; a plain read is only ordered behind the MFMA that produced its operand — too close: see above)
-          float va = aG[2 * pair][tb][e], ga = aG[2 * pair + 1][tb][e];
-          asm volatile("" : "+v"(va), "+v"(ga));
+          // The value / gate accumulators of a (hidden half, token block) are "redefined" IN PLACE by an empty asm when
+          // their first element is taken (volatile asm statements keep their order: this one sits behind the MFMAs issued
+          // so far, two slots after the block's last one), and every element is read from the redefined vectors.  Not a
+          // per-element "+v" pin on a scalar copy: hipcc materialised that copy with a v_mov it was free to hoist right
+          // behind the producing MFMA — a VALU read of a matrix-pipe result that is not there yet (nothing pads an asm
+          // MFMA's hazards): two registers of one token block wrong, in the builds where the allocator chose to copy.
+          if constexpr (e == 0) asm volatile("" : "+v"(aG[2 * pair][tb]), "+v"(aG[2 * pair + 1][tb]));
+          const float va = aG[2 * pair][tb][e], ga = aG[2 * pair + 1][tb][e];
           e_va[k] = va;
           e_g[k] = ga;
           res = __builtin_amdgcn_fmed3f(ga, -GL::R, GL::R);
@@ -365,10 +482,9 @@ __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
       if constexpr (KIND == 2) {
         if (has_next) {
           if constexpr ((FF_ABL & 1) == 0) {
-#pragma unroll
-            for (int n = 0; n < 10; ++n) dma(gsrc1 + (wave * 10 + n) * 1024, w1dst + (wave * 10 + n) * 1024);
+            ff_static_for<0, 10>([&](auto Nn) { dma(gsrc1 + wave * 10240, w1dst + wave * 10240, Nn); });
           }
-          load_x(Xn, m_next);
+          if constexpr (!LN) load_x(Xn, m_next);
         }
         if constexpr (has2) {
           ff_static_for<0, 6>([&](auto Cb) { fetch_r2(decltype(Cb)::value); });
@@ -382,6 +498,27 @@ __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
       ff_static_for<(KIND == 2 ? 40 - FB : 0), 60>([&](auto S) {
         constexpr int s = decltype(S)::value;
         constexpr int b = s / FB, j = s % FB;
+        // Keep-alive pins.  hipcc considers an asm statement's inputs dead at the statement and hands their registers to the
+        // next VALU result — while the matrix pipe is still reading them (sources are read over several cycles; C over all
+        // passes).  Every MFMA source is therefore named once more, as an input of an empty asm, at a point that is at least
+        // one MFMA later: the fragment of slot s - 1 behind the first MFMA of slot s, the bias vectors two slots after
+        // their MFMAs; H's last readers (slot 59) carry their wait states inside the asm string.  tools/ff_isa_audit.py checks
+        // the generated code for it.
+        auto behind_first_mfma = [&]() {
+          if constexpr (s > (KIND == 2 ? 40 : 0)) asm volatile("" ::"v"(fr[((s - 1) / FB) & 1][(s - 1) % FB]));
+          else if constexpr (KIND != 0 && s == 0) asm volatile("" ::"v"(fr[((60 - 1) / FB) & 1][(60 - 1) % FB]));
+          if constexpr (j == 0) {      // the next batch's reads go into the buffer the previous slot's fragment sat in: after its pin
+            // (first iteration: no W2 reads; last: no W1 reads, and nothing is read ahead for the next tile before its barrier)
+            if constexpr ((FF_ABL & 64) == 0 && !(KIND == 0 && s + FB >= 40 && s + FB < 60) && !(KIND == 2 && s + FB >= 60)) {
+#pragma unroll
+              for (int jj = 0; jj < FB; ++jj) {
+                const int sn = (s + FB + jj) % 60;      // (the last batch of an iteration reads batch 0 of the next)
+                const int base = s + FB >= 60 ? w1rd_next : (sn < 40 ? w1rd : w2rd);
+                fr[(b + 1) & 1][jj] = *(const f16x8*)(smem + base + frag_off(sn));
+              }
+            }
+          }
+        };
         if constexpr (j == 0) {
           // one wait for the whole batch (the pin names all of its fragments), then the next batch's reads
           if constexpr (KIND != 2 || s >= 40) {
@@ -392,17 +529,15 @@ __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
               asm volatile("" : "+v"(fr[b & 1][0]), "+v"(fr[b & 1][1]), "+v"(fr[b & 1][2]), "+v"(fr[b & 1][3]),
                            "+v"(fr[b & 1][4]), "+v"(fr[b & 1][5]));
           }
-          // (first iteration: no W2 reads; last: no W1 reads, and nothing is read ahead for the next tile before its barrier)
-          if constexpr ((FF_ABL & 64) == 0 && !(KIND == 0 && s + FB >= 40 && s + FB < 60) && !(KIND == 2 && s + FB >= 60)) {
-#pragma unroll
-            for (int jj = 0; jj < FB; ++jj) {
-              const int sn = (s + FB + jj) % 60;      // (the last batch of an iteration reads batch 0 of the next)
-              const int base = s + FB >= 60 ? w1rd_next : (sn < 40 ? w1rd : w2rd);
-              fr[(b + 1) & 1][jj] = *(const f16x8*)(smem + base + frag_off(sn));
-            }
-          }
         }
-        if constexpr (KIND == 2 && s < 40) return;
+        if constexpr (KIND == 2 && s < 40) {
+          behind_first_mfma();      // (no MFMA in these slots: the read-ahead of the first W2 batch)
+          return;
+        }
+        if constexpr (KIND == 0 && s >= 40) behind_first_mfma();      // (no GEMM2 in the first iteration)
+        if constexpr (KIND != 2 && (s == 3 || s == 23)) {
+          asm volatile("" ::"v"(bias[s == 3 ? 0 : 2]), "v"(bias[s == 3 ? 1 : 3]));      // C operands of the k-step-0 MFMAs two slots back
+        }
         if constexpr (s == 14 && KIND != 2) {
           bias[2] = *(const f32x4*)(smem + b1rd + 128);
           bias[3] = *(const f32x4*)(smem + b1rd + 192);
@@ -414,7 +549,7 @@ __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
         const f16x8 a = fr[b & 1][j];
         if constexpr (s < 40) {
           constexpr int rb = 2 * (s / 20) + (s & 1), ks = (s % 20) / 2;
-          if constexpr (KIND == 0 && s < 20) {      // the residual of channel block s -> accumulators (landed by this iteration's vmcnt(0))
+          if constexpr (KIND == 0 && s < 20 && !LN) {      // the residual of channel block s -> accumulators (landed by this iteration's vmcnt(0))
 #pragma unroll
             for (int tb = 0; tb < T; ++tb) {
               if constexpr ((FF_ABL & 1024) != 0) out[s][tb] = f32x4{0.f, 0.f, 0.f, 0.f};      // (probe: no residual loads)
@@ -428,9 +563,15 @@ __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
               if (ks == 0) aG[rb][tb] = bias[rb] + __builtin_bit_cast(f32x4, a);
             } else if constexpr (ks == 0) {
               asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(aG[rb][tb]) : "v"(a), "v"(X[tb][ks]), "v"(bias[rb]));
+            } else if constexpr (ks == 9) {
+              // the LAST MFMA of an accumulator's chain carries the result's wait states inside the string: from here on the
+              // value is a finished one for hipcc, whose register allocator may copy it (live-range splitting) in the very
+              // next instruction — it did, and read two registers the matrix pipe had not written yet
+              asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\ts_nop 7" : "+v"(aG[rb][tb]) : "v"(a), "v"(X[tb][ks]));
             } else {
               asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(aG[rb][tb]) : "v"(a), "v"(X[tb][ks]));
             }
+            if constexpr (tb == 0) behind_first_mfma();
             after_mfma(Kind, std::integral_constant<int, s * T + tb>{});
           });
         } else {
@@ -441,7 +582,14 @@ __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
             //  accumulate chain: no wait states needed; a channel block is read two slots = 2 T MFMAs after its last one)
             if constexpr (KIND != 0) {
               if constexpr ((FF_ABL & 16) != 0) asm volatile("" : "+a"(out[cb][tb]) : "v"(a), "v"(Hcur[tb]));
+              else if constexpr (s == 59 || KIND == 2)
+                // the LAST readers of H(i-1) and of this iteration's last fragment: the wait states that keep the next VALU
+                // write out of the registers the matrix pipe is reading go INTO the string (no pin survives the loop's
+                // back edge: hipcc places the copies that start the next H right behind this statement)
+                // (and, in the last iteration, every one: it is the last writer of its channel block)
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\ts_nop 7" : "+a"(out[cb][tb]) : "v"(a), "v"(Hcur[tb]));
               else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(out[cb][tb]) : "v"(a), "v"(Hcur[tb]));
+              if constexpr (tb == 0) behind_first_mfma();
             }
             after_mfma(Kind, std::integral_constant<int, s * T + tb>{});
           });
@@ -454,10 +602,10 @@ __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
         if constexpr ((FF_ABL & 1) != 0 || KIND == 2) {
         } else if constexpr (s % FF_DMA_EVERY == 1 && s < 10 * FF_DMA_EVERY) {
           constexpr int n = s / FF_DMA_EVERY;
-          dma(gsrc1 + (wave * 10 + n) * 1024, w1dst + (wave * 10 + n) * 1024);
+          dma(gsrc1 + wave * 10240, w1dst + wave * 10240, std::integral_constant<int, n>{});
         } else if constexpr (s % FF_DMA_EVERY == 1 && s < 15 * FF_DMA_EVERY) {
           constexpr int n = s / FF_DMA_EVERY - 10;
-          dma(gsrc2 + (wave * 5 + n) * 1024, w2dst + (wave * 5 + n) * 1024);
+          dma(gsrc2 + wave * 5120, w2dst + wave * 5120, std::integral_constant<int, n>{});
         }
         if constexpr (KIND == 0 && s == 20) FF_STAMP(10);
         if constexpr (KIND == 0 && s == 40) FF_STAMP(11);
@@ -479,8 +627,45 @@ __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
 
     iteration(std::integral_constant<int, 0>{}, 0);
     FF_STAMP(2);
-    for (int i = 1; i < FF_NCH; ++i) iteration(std::integral_constant<int, 1>{}, i);
+#if defined(FF_DEBUGX) && FF_DEBUGX == 3
+    if (p.dbg && tile0 == (int)blockIdx.x) {      // probe: the accumulators after the first iteration (= the residual they started from)
+      f32x4* d = (f32x4*)p.dbg + ((size_t)blockIdx.x * 256 + t) * (T * 20);
+#pragma unroll
+      for (int tb = 0; tb < T; ++tb)
+#pragma unroll
+        for (int cb = 0; cb < 20; ++cb) {
+          asm volatile("" : "+a"(out[cb][tb]));
+          d[tb * 20 + cb] = out[cb][tb];
+        }
+    }
+#endif
+#if defined(FF_DEBUGX) && FF_DEBUGX == 2
+    if (p.dbg && tile0 == (int)blockIdx.x) {      // probe: the operand fragments again, after the first iteration
+      f16x8* d = (f16x8*)p.dbg + ((size_t)blockIdx.x * 256 + t) * (T * 10);
+#pragma unroll
+      for (int tb = 0; tb < T; ++tb)
+#pragma unroll
+        for (int ks = 0; ks < 10; ++ks) d[tb * 10 + ks] = X[tb][ks];
+    }
+#endif
+    for (int i = 1; i < FF_NCH; ++i) {
+      iteration(std::integral_constant<int, 1>{}, i);
+#if defined(FF_DEBUGX) && FF_DEBUGX == 4
+      if (i == 1 && p.dbg && tile0 == (int)blockIdx.x) {      // probe: H(0) as GEMM2 received it
+        u32x4* d = (u32x4*)p.dbg + ((size_t)blockIdx.x * 256 + t) * T;
+#pragma unroll
+        for (int tb = 0; tb < T; ++tb) d[tb] = Hcur[tb];
+      }
+#endif
+    }
     FF_STAMP(3);
+#if defined(FF_DEBUGX) && FF_DEBUGX == 5
+    if (p.dbg && tile0 == (int)blockIdx.x) {      // probe: H(38) as GEMM2 received it in iteration 39
+      u32x4* d = (u32x4*)p.dbg + ((size_t)blockIdx.x * 256 + t) * T;
+#pragma unroll
+      for (int tb = 0; tb < T; ++tb) d[tb] = Hcur[tb];
+    }
+#endif
     iteration(std::integral_constant<int, 2>{}, FF_NCH);
     FF_STAMP(4);
     // Tile boundary: the next tile's W1(0) pieces and X fragments were requested BEFORE this tile's stores; loads return in
@@ -491,11 +676,13 @@ __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
     else asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     FF_STAMP(5);
+    if constexpr (!LN) {
 #pragma unroll
-    for (int tb = 0; tb < T; ++tb)
+      for (int tb = 0; tb < T; ++tb)
 #pragma unroll
-      for (int ks = 0; ks < 10; ++ks) X[tb][ks] = Xn[tb][ks];
-    pin_x();
+        for (int ks = 0; ks < 10; ++ks) X[tb][ks] = Xn[tb][ks];
+      pin_x();
+    }
     par ^= 1;
   }
 }
@@ -503,9 +690,10 @@ __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
 // Fragment-order packing of one FeedForward's weights (once per parameter version).
 //   w1: [2560][320] fp16 in pack_geglu row order (32-row blocks of 16 value + 16 gate rows), w2: [320][1280] fp16
 //   Wp: [41][60][64][8]: chunk j, fragment f, lane l:
-//     f < 40:  rb = f / 10, ks = f % 10:  w1[64 j + 16 rb + (l & 15)][32 ks + 8 (l >> 4) + 0..7]
+//     f < 40:  rb = f / 10, ks = f % 10:  w1[64 j + 16 rb + (l & 15)][32 ks + 8 (l >> 4) + 0..7]   (kperm = 0)
+//                                         w1[..][32 ks + 16 (q >> 2) + 4 (l >> 4) + (q & 3)], q = 0..7  (kperm = 1: the LN kernels)
 //     f >= 40: cb = f - 40:               w2[16 cb + (l & 15)][32 j + hp(l >> 4, 0..7)],  hp(g, p) = p < 4 ? 4 g + p : 12 + 4 g + p
-__global__ void ff_pack_kernel(const f16* __restrict__ w1, const f16* __restrict__ w2, f16* __restrict__ Wp) {
+__global__ void ff_pack_kernel(const f16* __restrict__ w1, const f16* __restrict__ w2, f16* __restrict__ Wp, int kperm) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // one 16-byte lane entry each
   if (idx >= (FF_NCH + 1) * 60 * 64) return;
   const int l = idx & 63, f = (idx >> 6) % 60, jj = idx / (60 * 64);
@@ -514,7 +702,13 @@ __global__ void ff_pack_kernel(const f16* __restrict__ w1, const f16* __restrict
   f16x8 v;
   if (f < 40) {
     const int rb = f / 10, ks = f % 10;
-    v = *(const f16x8*)(w1 + (int64_t)(64 * j + 16 * rb + r) * FF_C + 32 * ks + 8 * g);
+    const f16* row = w1 + (int64_t)(64 * j + 16 * rb + r) * FF_C + 32 * ks;
+    if (kperm) {      // position q of lane group g <-> channel 16 (q >> 2) + 4 g + (q & 3) of the k-step: the accumulator layout's strips
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = row[16 * (q >> 2) + 4 * g + (q & 3)];
+    } else {
+      v = *(const f16x8*)(row + 8 * g);
+    }
   } else {
     const int cb = f - 40;
     const f16* src = w2 + (int64_t)(16 * cb + r) * FF_HID + 32 * j;

@@ -241,7 +241,8 @@ class UNetEngine:
             w1, b1 = packing.pack_geglu(ff.net[0].proj.weight, ff.net[0].proj.bias)
             d = dict(w1=w1, b1=b1, w2=packing.pack_linear(ff.net[2].weight), b2=_f32(ff.net[2].bias))
             if w1.is_cuda and tuple(w1.shape) == (2560, 320) and tuple(d["w2"].shape) == (320, 1280):
-                d["wp"] = ops.ff_pack(w1, d["w2"])     # the one-kernel FeedForward's fragment-order weight stream
+                # the one-kernel LayerNorm + FeedForward's fragment-order weight stream (K order of the LayerNorm form)
+                d["wp"] = ops.ff_pack(w1, d["w2"], for_ln=True)
             return d
 
         def pack_attn(att, q_scale=1.0):
@@ -462,19 +463,22 @@ class UNetEngine:
         ws.release(a16)
         return xs
 
+    def _ff_ln(self, F, x32, affine, M, *, out, r2=None, frame_alpha=None, rows_per_alpha=1, out_kind=OUT_F32,
+               addvec=None, rows_per_vec=1) -> bool:
+        """x = ff(norm(x32 + addvec)) + (x32 + addvec) [blended with r2] as ONE launch (ff_fused_kernel.h, the LayerNorm
+        form): the LayerNorm kernel, its fp16 output and the 660 MB hidden tensor never touch memory.  False = not taken
+        (another level, too few tokens, switched off): the caller runs LayerNorm + two GEMMs."""
+        if "wp" not in F or self.fuse_layernorm or not ops.ff_fused_ok(M, F["w1"].shape[1], F["w1"].shape[0] // 2):
+            return False
+        ln = dict(gamma=affine[0], beta=affine[1], addvec=addvec, rows_per_vec=rows_per_vec)
+        kw = dict(r2=r2, out_kind=out_kind, frame_alpha=frame_alpha, rows_per_alpha=rows_per_alpha, ln=ln)
+        if _ZIGZAG in (1, 2):
+            kw["sched"] = self._next_dir()
+        ops.ff_fused(x32, F["wp"], F["b1"], F["b2"], out, M=M, **kw)
+        return True
+
     def _ff(self, F, a16, M, **epi):
         ws = self.ws
-        if "wp" in F and epi.get("ln") is None and ops.ff_fused_ok(M, F["w1"].shape[1], F["w1"].shape[0] // 2) \
-                and epi.get("r1") is not None and (epi.get("frame_alpha") is None or epi.get("r1_blend")) \
-                and (epi.get("r2") is None) == (epi.get("frame_alpha") is None):
-            # FeedForward + residual(s) as ONE launch: the hidden tensor never leaves the CU (ff_fused_kernel.h)
-            kw = dict(r1=epi["r1"], r2=epi.get("r2"), out_kind=epi.get("out_kind", OUT_F32),
-                      frame_alpha=epi.get("frame_alpha"), rows_per_alpha=epi.get("rows_per_alpha", 1))
-            if _ZIGZAG in (1, 2):
-                kw["sched"] = self._next_dir()
-            ops.ff_fused(a16, F["wp"], F["b1"], F["b2"], epi["out"], M=M, **kw)
-            ws.release(a16)
-            return
         hid = ws.alloc((M, F["w1"].shape[0] // 2), torch.float16)
         # the hidden tensor only lives between these two GEMMs: where both run on the ping-pong kernel it
         # is kept tile-blocked ([M/256][N/320][256][160]: whole 128-byte lines per store, §7 of DESIGN.md)
@@ -527,14 +531,17 @@ class UNetEngine:
             self._gemm(ao, sb["attn"]["wo"], xs, M=M, bias=sb["attn"]["bo"], r1=xs,
                      rowvec=ca[sb["ca"]], rows_per_vec=HW, ln=req)
             ws.release(ao)
-            a16 = nxt if fuse else self._ln(xs, sb["ln3"])
             # ---- temporal VideoTransformerBlock (video_attention.py:109-140) on x + frame pos-emb ----
             xm = ws.alloc((M, Cc), torch.float32)
-            nxt, req = ln_req(tb["ln_in"], addvec=pos, rows_per_vec=HW, sum_out=xm)
-            self._ff(sb["ff"], a16, M, out=xs, r1=xs, ln=req)
-            a16 = nxt if fuse else self._ln(xs, tb["ln_in"], addvec=pos, rows_per_vec=HW, sum_out=xm)
-            nxt, req = ln_req(tb["ln1"])
-            self._ff(tb["ff_in"], a16, M, out=xm, r1=xm, ln=req)
+            if not self._ff_ln(sb["ff"], xs, sb["ln3"], M, out=xs):                  # x = ff(norm3(x)) + x
+                a16 = nxt if fuse else self._ln(xs, sb["ln3"])
+                nxt, req = ln_req(tb["ln_in"], addvec=pos, rows_per_vec=HW, sum_out=xm)
+                self._ff(sb["ff"], a16, M, out=xs, r1=xs, ln=req)
+            # x_mix = x + pos; x_mix = ff_in(norm_in(x_mix)) + x_mix
+            if not self._ff_ln(tb["ff_in"], xs, tb["ln_in"], M, out=xm, addvec=pos, rows_per_vec=HW):
+                a16 = nxt if fuse else self._ln(xs, tb["ln_in"], addvec=pos, rows_per_vec=HW, sum_out=xm)
+                nxt, req = ln_req(tb["ln1"])
+                self._ff(tb["ff_in"], a16, M, out=xm, r1=xm, ln=req)
             a16 = nxt if fuse else self._ln(xm, tb["ln1"])
             qkv = ws.alloc((M, 3 * Cc), torch.float16)
             self._gemm(a16, tb["attn"]["wqkv"], qkv, M=M, out_kind=OUT_F16)
@@ -547,11 +554,16 @@ class UNetEngine:
             self._gemm(ao, tb["attn"]["wo"], xm, M=M, bias=tb["attn"]["bo"], r1=xm,
                      rowvec=ca[tb["ca"]], rows_per_vec=T * HW, ln=req)
             ws.release(ao)
-            a16 = nxt if fuse else self._ln(xm, tb["ln3"])
             # x = alpha*x + (1-alpha)*(ff(...) + x_mix)   (AlphaBlender, video_attention.py:289-293)
             final = bi == len(blocks) - 1
-            if final:   # only proj_out reads the result: emit it as the fp16 GEMM operand directly
+            if final:
                 last = ws.alloc((M, Cc), torch.float16)
+            if self._ff_ln(tb["ff"], xm, tb["ln3"], M, out=last if final else xs, r2=xs, out_kind=OUT_F16 if final else OUT_F32,
+                           frame_alpha=st["alphas"][L["blend"]], rows_per_alpha=HW):
+                ws.release(xm)
+                continue
+            a16 = nxt if fuse else self._ln(xm, tb["ln3"])
+            if final:   # only proj_out reads the result: emit it as the fp16 GEMM operand directly
                 self._ff(tb["ff"], a16, M, out=last, out_kind=OUT_F16, r1=xm, r2=xs,
                          frame_alpha=st["alphas"][L["blend"]], rows_per_alpha=HW, r1_blend=True)
             else:

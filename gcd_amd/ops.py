@@ -218,27 +218,40 @@ def ff_fused_ok(M: int, C_: int, hidden: int, enabled: Optional[bool] = None) ->
     return bool(on and M >= FF_FUSED_MIN_TOKENS and _lib.load().gcd_ff_fused_supported(M, C_, hidden))
 
 
-def ff_pack(w1_geglu16: torch.Tensor, w2_16: torch.Tensor) -> torch.Tensor:
+def ff_pack(w1_geglu16: torch.Tensor, w2_16: torch.Tensor, for_ln: bool = False) -> torch.Tensor:
     """The fragment-order weight stream of one FeedForward (gcd_ff_pack_f16): w1 = packing.pack_geglu's fp16
-    [2560, 320], w2 = fp16 [320, 1280].  Once per parameter version."""
+    [2560, 320], w2 = fp16 [320, 1280].  Once per parameter version.  for_ln: for `ff_fused(..., ln=...)`."""
     _need_gpu(w1_geglu16, w2_16)
     assert w1_geglu16.dtype == w2_16.dtype == torch.float16 and w1_geglu16.is_contiguous() and w2_16.is_contiguous()
     assert tuple(w1_geglu16.shape) == (2560, 320) and tuple(w2_16.shape) == (320, 1280)
     lib = _lib.load()
     wp = torch.empty(int(lib.gcd_ff_packed_bytes()) // 2, device=w1_geglu16.device, dtype=torch.float16)
-    check(lib.gcd_ff_pack_f16(w1_geglu16.data_ptr(), w2_16.data_ptr(), wp.data_ptr(), _stream()), "gcd_ff_pack_f16")
+    check(lib.gcd_ff_pack_f16(w1_geglu16.data_ptr(), w2_16.data_ptr(), wp.data_ptr(), int(for_ln), _stream()),
+          "gcd_ff_pack_f16")
     return wp
 
 
-def ff_fused(x16: torch.Tensor, wp: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor, out: torch.Tensor, *, M: int,
-             r1: torch.Tensor, r2: Optional[torch.Tensor] = None, out_kind: int = OUT_F32, s_acc: float = 1.0,
-             s_r2: float = 1.0, frame_alpha=None, rows_per_alpha: int = 1, sched: int = 0):
-    """out = s_acc (FF(x16) + r1) + s_r2 r2 in one kernel (gcd_ff_desc); frame_alpha: s_acc = 1 - alpha, s_r2 = alpha."""
-    _need_gpu(x16, wp, b1, b2, out, r1, r2, frame_alpha)
-    assert x16.dtype == torch.float16 and out.dtype == (torch.float32 if out_kind == OUT_F32 else torch.float16)
+def ff_fused(x: torch.Tensor, wp: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor, out: torch.Tensor, *, M: int,
+             r1: Optional[torch.Tensor] = None, r2: Optional[torch.Tensor] = None, out_kind: int = OUT_F32,
+             s_acc: float = 1.0, s_r2: float = 1.0, frame_alpha=None, rows_per_alpha: int = 1, sched: int = 0, ln=None):
+    """out = s_acc (FF(x16) + r1) + s_r2 r2 in one kernel (gcd_ff_desc); frame_alpha: s_acc = 1 - alpha, s_r2 = alpha.
+    ln = dict(gamma, beta[, eps, addvec, rows_per_vec]): the LayerNorm form — x is the fp32 residual stream,
+    z = x + addvec, out = s_acc (FF(LN(z)) + z) + s_r2 r2 (wp from ff_pack(..., for_ln=True); r1 must be None)."""
+    _need_gpu(x, wp, b1, b2, out, r1, r2, frame_alpha)
+    assert out.dtype == (torch.float32 if out_kind == OUT_F32 else torch.float16)
     d = FfDesc()
-    d.X, d.ldx, d.wp, d.b1, d.b2 = x16.data_ptr(), _ld(x16), wp.data_ptr(), b1.data_ptr(), b2.data_ptr()
-    d.R1, d.ldr1 = r1.data_ptr(), _ld(r1)
+    d.wp, d.b1, d.b2 = wp.data_ptr(), b1.data_ptr(), b2.data_ptr()
+    if ln is not None:
+        assert x.dtype == torch.float32 and r1 is None
+        _need_gpu(ln["gamma"], ln["beta"], ln.get("addvec"))
+        d.x32, d.ldx32 = x.data_ptr(), _ld(x)
+        d.ln_gamma, d.ln_beta, d.ln_eps = ln["gamma"].data_ptr(), ln["beta"].data_ptr(), ln.get("eps", 1e-5)
+        if ln.get("addvec") is not None:
+            d.addvec, d.ld_addvec, d.rows_per_vec = ln["addvec"].data_ptr(), _ld(ln["addvec"]), ln["rows_per_vec"]
+    else:
+        assert x.dtype == torch.float16 and r1 is not None
+        d.X, d.ldx = x.data_ptr(), _ld(x)
+        d.R1, d.ldr1 = r1.data_ptr(), _ld(r1)
     if r2 is not None:
         d.R2, d.ldr2 = r2.data_ptr(), _ld(r2)
     d.out, d.ldo, d.out_kind = out.data_ptr(), _ld(out), out_kind

@@ -199,7 +199,7 @@ int gcd_gemm_hidden_blocked_supported(int M, int N_geglu, int N_out);
  * blended term — gcd_gemm_desc's r1_blend form).  Same arithmetic as gcd_gemm_f16(GCD_OUT_GEGLU) + gcd_gemm_f16 up to
  * fp32 summation order (R1 enters the accumulation first).                                                          */
 typedef struct gcd_ff_desc {
-  const void* X;            /* fp16 [M, 320] LayerNorm output, leading dimension ldx (elements)           */
+  const void* X;            /* fp16 [M, 320] LayerNorm output, leading dimension ldx (elements); NULL in the LN form */
   int64_t ldx;
   const void* wp;           /* gcd_ff_pack_f16 output (gcd_ff_packed_bytes() bytes)                        */
   const float* b1;          /* [2560] in the GEGLU row order of GCD_OUT_GEGLU (16 value / 16 gate)         */
@@ -216,11 +216,25 @@ typedef struct gcd_ff_desc {
   float s_acc, s_r2;        /* used when frame_alpha == NULL                                                */
   int32_t M, C, hidden;     /* C = 320, hidden = 1280                                                       */
   int32_t sched;            /* bit 0: walk the tiles from the end (as gcd_gemm_desc.sched)                  */
+  /* The LayerNorm form (ln_gamma != NULL; wp packed with for_ln = 1): the nn.LayerNorm in front of the FeedForward
+     (attention.py:519-521, 566-572; video_attention.py:50, 90-93, 109-140) is computed by the same kernel.
+        z = x32[m] + addvec[m / rows_per_vec]      (addvec: the x + time_pos_embed of video_attention.py:283-284, or NULL)
+        out = s_acc * ( FF( LN(z) * ln_gamma + ln_beta ) + z ) + s_r2 * R2
+     z is read once (fp32, 16-byte aligned rows) and is the residual: X and R1 must be NULL.  out may alias x32 or R2.  */
+  const float* x32;
+  int64_t ldx32;
+  const float* ln_gamma;
+  const float* ln_beta;
+  float ln_eps;
+  const float* addvec;
+  int64_t ld_addvec;
+  int32_t rows_per_vec;     /* multiple of 32                                                               */
 } gcd_ff_desc;
 int64_t gcd_ff_packed_bytes(void);
 /* w1: fp16 [2560, 320] in GCD_OUT_GEGLU row order, w2: fp16 [320, 1280] -> wp, the weights in MFMA-fragment order
- * (per 32-hidden-unit chunk 40 W1 fragments + 20 W2 fragments of 1 KB).  Once per parameter version.                */
-int gcd_ff_pack_f16(const void* w1, const void* w2, void* wp, void* stream);
+ * (per 32-hidden-unit chunk 40 W1 fragments + 20 W2 fragments of 1 KB).  Once per parameter version.  for_ln = 1:
+ * for the LayerNorm form (W1's K order follows the channel strips of the accumulator layout x32 is read in).        */
+int gcd_ff_pack_f16(const void* w1, const void* w2, void* wp, int for_ln, void* stream);
 int gcd_ff_fused_supported(int M, int C, int hidden);
 int gcd_ff_fused_f16(const gcd_ff_desc* desc, void* stream);
 

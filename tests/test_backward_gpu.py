@@ -613,13 +613,14 @@ def test_training_step_full_width_cfg4_vs_reference_golden(gpu, dtype, fixture, 
     # the UNMODIFIED reference under its own `bf16-mixed` arithmetic (torch.autocast(bfloat16), what cfg4's config runs;
     # oracle/make_autocast_bars.py on this fixture's inputs) is 7.7e-3 (output) / 9.1e-2 (gradients) away from its own fp32
     # run: tests/golden/autocast_bars.json.  This path (bf16 GEMM operands, fp32 everything else) measures 4.8e-3 on the
-    # gradients; its bar is 1.5x that measurement and, asserted below, well inside the reference's own bf16 distance.
-    tol_out, tol_g = (2e-3, 5e-3) if dtype == "fp16" else (1.5e-2, 7.5e-3)
+    # gradients and 4.4e-3 on the output; its bars are 1.5x those measurements and, asserted below, inside the reference's own
+    # bf16 distance.
+    tol_out, tol_g = (2e-3, 5e-3) if dtype == "fp16" else (7e-3, 7.5e-3)
     if dtype == "bf16":
         import json
         ref = json.loads((Path(__file__).resolve().parent / "golden" / "autocast_bars.json").read_text())[
             "cfg4_reference_bf16_autocast_vs_own_fp32"]
-        assert tol_g < 0.25 * ref["gradient_global_rel_l2"] and tol_out < 2 * ref["output_rel_l2"]
+        assert tol_g < 0.25 * ref["gradient_global_rel_l2"] and tol_out < ref["output_rel_l2"]
     if G["step"] > 0:
         tol_g *= 3.0
     e_out = rel_l2(sample(out.detach().cpu(), 65536), G["out_samples"])

@@ -349,6 +349,75 @@ def test_ff_fused_one_kernel(gpu, M, form):
         assert torch.equal(inpl, out)
 
 
+@pytest.mark.parametrize("M,form", [(128 * 256 + 77, "plain"), (9216 * 3, "pos"), (9216 * 2, "blend16"), (5, "plain")])
+def test_ff_fused_with_its_layernorm(gpu, M, form):
+    """The form the engine uses: x = ff(norm(x + pos)) + (x + pos) [AlphaBlender with a second stream] as ONE launch from the
+    fp32 residual stream (gcd_ff_desc.ln_gamma != NULL) — the nn.LayerNorm in front of the FeedForward (attention.py:519-521,
+    566-572; video_attention.py:90-93, 109-140, 283-284) is computed by the kernel, whose accumulators start from the very
+    values it normalises.  Against fp32 torch (LayerNorm output and hidden tensor rounded to fp16 where the HIP paths round
+    them) and against LayerNorm kernel + two GEMMs; in place, as the engine calls it."""
+    from gcd_amd import ops, packing
+    g = _gen(612)
+    C, H = 320, 1280
+    x = torch.randn(M, C, generator=g) * 1.5 + 0.3
+    w1 = _h(torch.randn(2 * H, C, generator=g) / math.sqrt(C))
+    b1 = torch.randn(2 * H, generator=g) * 0.5
+    w2 = _h(torch.randn(C, H, generator=g) / math.sqrt(H))
+    b2 = torch.randn(C, generator=g)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g) * 0.5
+    r2 = torch.randn(M, C, generator=g)
+    rpv = 9216
+    nvec = (M + rpv - 1) // rpv
+    pos = torch.randn(nvec, C, generator=g) * 0.7
+    alpha = torch.rand(nvec, generator=g)
+    z = x + pos.repeat_interleave(rpv, 0)[:M] if form != "plain" else x
+    xn = _h(F.layer_norm(z, (C,), gamma, beta, 1e-5))
+    h = xn @ w1.t() + b1
+    hid = _h(h[:, :H] * F.gelu(h[:, H:]))
+    ff = hid @ w2.t() + b2
+    if form == "blend16":
+        a = alpha.repeat_interleave(rpv)[:M, None]
+        ref = (1 - a) * (ff + z) + a * r2
+    else:
+        ref = ff + z
+    w1p, b1p = packing.pack_geglu(w1.to(gpu), b1.to(gpu))
+    w2p = w2.half().to(gpu)
+    wp = ops.ff_pack(w1p, w2p, for_ln=True)
+    xg, r2g, b2g, gg, bg = x.to(gpu), r2.to(gpu), b2.to(gpu), gamma.to(gpu), beta.to(gpu)
+    ln = dict(gamma=gg, beta=bg)
+    if form != "plain":
+        ln.update(addvec=pos.to(gpu), rows_per_vec=rpv)
+    kind = ops.OUT_F16 if form == "blend16" else ops.OUT_F32
+    out = torch.empty(M, C, device=gpu, dtype=torch.float16 if form == "blend16" else torch.float32)
+    kw = dict(r2=r2g, out_kind=kind, frame_alpha=alpha.to(gpu), rows_per_alpha=rpv) if form == "blend16" else {}
+    ops.ff_fused(xg, wp, b1p, b2g, out, M=M, ln=ln, **kw)
+    # LayerNorm kernel + two GEMMs
+    x16 = torch.empty(M, C, device=gpu, dtype=torch.float16)
+    zg = torch.empty(M, C, device=gpu) if form != "plain" else xg
+    ops.layernorm(xg, gg, bg, x16, addvec=ln.get("addvec"), rows_per_vec=rpv, sum_out=zg if form != "plain" else None)
+    hid16 = torch.empty(M, H, device=gpu, dtype=torch.float16)
+    two = torch.empty_like(out)
+    ops.gemm(x16, w1p, hid16, M=M, bias=b1p, out_kind=ops.OUT_GEGLU)
+    if form == "blend16":
+        ops.gemm(hid16, w2p, two, M=M, bias=b2g, r1=zg, r2=r2g, out_kind=kind, frame_alpha=alpha.to(gpu), rows_per_alpha=rpv,
+                 r1_blend=True)
+    else:
+        ops.gemm(hid16, w2p, two, M=M, bias=b2g, r1=zg)
+    torch.cuda.synchronize()
+    e, e2 = rel_l2(out.float(), ref), rel_l2(out.float(), two.float())
+    print(f"LayerNorm + FeedForward in one launch, M = {M} {form}: vs fp32 torch {e:.2e}, vs LayerNorm kernel + two GEMMs {e2:.2e}")
+    # (a last-bit difference of the fp32 statistics flips an fp16 rounding of the normalised operand here and there: 1e-4)
+    assert e < (TOL_F16 if form == "blend16" else 3e-4), f"rel-L2 {e:.3e}"
+    assert e2 < (6e-4 if form == "blend16" else 2e-4), f"vs the three-launch path {e2:.3e}"
+    if form == "plain":      # in place: out aliases the stream it reads
+        inpl = xg.clone()
+        ops.ff_fused(inpl, wp, b1p, b2g, inpl, M=M, ln=ln)
+        torch.cuda.synchronize()
+        assert torch.equal(inpl, out)
+    with pytest.raises(AssertionError):                    # the LayerNorm form has no separate residual operand
+        ops.ff_fused(xg, wp, b1p, b2g, out, M=M, ln=ln, r1=xg, **kw)
+
+
 def test_ff_fused_refuses_what_it_cannot_do(gpu):
     from gcd_amd import ops, _lib
     x = torch.zeros(256, 320, device=gpu, dtype=torch.float16)

@@ -440,6 +440,12 @@ def test_two_plans_alternating_in_one_process_do_not_interfere(gpu):
         return out.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
     oa, ga = alone(na, ia)
     ob, gb = alone(nb, ib)
+    # run-to-run spread of a network stepped ALONE (the few reductions that use atomics are order-dependent): the bar for
+    # "the same gradients" below is bit equality where a lone repeat is bit-equal, else that spread
+    _, ga2 = alone(na, ia)
+    spread = max((rel_l2(ga2[n], ga[n]) for n in ga if ga[n].numel() >= 64), default=0.0)
+    lone_bit_equal = all(torch.equal(ga2[n], ga[n]) for n in ga)
+    print(f"a lone repeat: bit-equal {lone_bit_equal}, worst tensor rel-L2 {spread:.2e}")
     heard = []
     TP.add_grad_listener(list(na.parameters()), heard.append)
     try:
@@ -454,10 +460,17 @@ def test_two_plans_alternating_in_one_process_do_not_interfere(gpu):
     finally:
         TP.remove_grad_listener(list(na.parameters()), heard.append)
     assert torch.equal(out_a, oa) and torch.equal(out_b, ob)
+    worst = ("", 0.0)
     for net, ref in ((na, ga), (nb, gb)):
         for n, p in net.named_parameters():
             if n in ref:
-                assert torch.equal(p.grad, ref[n]), n
+                if lone_bit_equal:
+                    assert torch.equal(p.grad, ref[n]), n
+                elif ref[n].numel() >= 64:
+                    e = rel_l2(p.grad, ref[n])
+                    worst = max(worst, (n, e), key=lambda t: t[1])
+    print(f"alternating vs alone: worst tensor {worst[0]} rel-L2 {worst[1]:.2e}")
+    assert worst[1] <= max(10 * spread, 1e-6)
     ids_a, ids_b = {id(p) for p in na.parameters()}, {id(p) for p in nb.parameters()}
     assert heard and all(id(p) in ids_a for p in heard) and not any(id(p) in ids_b for p in heard)
     assert A._sink() is None

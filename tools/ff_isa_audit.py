@@ -9,8 +9,11 @@ what a compiler scheduling or register-allocation change could silently break:
   2. no VALU / VMEM / LDS instruction writes a VGPR that an MFMA reads as its A, B or C operand within the 2
      instructions in front of that MFMA (VALU write -> MFMA source read needs wait states nothing inserts inside asm) —
      except LDS / VMEM loads, which the compiler's own s_waitcnt covers;
-  3. no VALU instruction reads an MFMA's result within the 2 instructions behind it (a 4-pass MFMA's result needs
-     7 wait states before a VALU reads it);
+  3. no VALU instruction reads an MFMA's result within the 10 instructions behind it, unless the accumulate chain has
+     taken the result over (a 4-pass MFMA's result needs 7 wait states before a VALU reads it; this is what a
+     compiler-inserted copy of an accumulator — live-range splitting, a scalar "+v" pin — trips over);
+  3b. no VALU instruction WRITES a register an MFMA reads as A, B (or as a C that is not its own result) within the 2 instructions behind that MFMA (the
+     matrix pipe reads its sources over several cycles; hipcc believes an asm statement's inputs dead at the statement);
   4. no `s_waitcnt vmcnt(N)` with N < 40 inside the first iteration's code other than the kernel's own vmcnt(0)
      (a compiler-inserted counted wait there would drain the residual loads it cannot see: 9 instead of 60 memory
      instructions in flight per wave, measured 17 000 cycles per tile).
@@ -35,6 +38,10 @@ def compile_to_asm(out: Path) -> None:
     cmd = [B._hipcc(), *B.FLAGS, *B.EXTRA_FLAGS.get("ff_fused.hip", []), "--cuda-device-only", "-S",
            str(B.CSRC / "ff_fused.hip"), "-o", str(out)]
     subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+
+
+AUDIT_BACK = int(__import__("os").environ.get("FF_AUDIT_BACK", "2"))
+AUDIT_FWD = int(__import__("os").environ.get("FF_AUDIT_FWD", "10"))
 
 
 def regs(op: str):
@@ -78,7 +85,7 @@ def audit_kernel(name: str, lines: list[str]) -> list[str]:
             continue
         src = set().union(*(regs(o) for o in ops[1:]))
         dst = regs(ops[0])
-        for back in (1, 2):
+        for back in range(1, AUDIT_BACK + 1):
             if k - back < 0:
                 break
             pop, pops = ins[k - back][1]
@@ -87,10 +94,24 @@ def audit_kernel(name: str, lines: list[str]) -> list[str]:
             if pops and regs(pops[0]) & src and pop.startswith("v_"):
                 errs.append(f"{name}: {pop} writes {pops[0]} {back} instruction(s) in front of the MFMA that reads it "
                             f"(line {i + 1})")
+        ab = set().union(*(regs(o) for o in ops[1:4] if regs(o) != dst))      # A, B and a C that is not the accumulate chain
         for fwd in (1, 2):
             if k + fwd >= len(ins):
                 break
             nop, nops = ins[k + fwd][1]
+            if nop == "s_nop" and nops and int(nops[0]) >= 3:
+                break      # wait states inside the asm string: whatever follows is far enough
+            if nop.startswith("v_") and not nop.startswith("v_mfma") and nops and regs(nops[0]) & ab:
+                errs.append(f"{name}: {nop} writes {nops[0]}, a source of the MFMA {fwd} instruction(s) in front of it "
+                            f"(line {i + 1})")
+        for fwd in range(1, AUDIT_FWD + 1):
+            if k + fwd >= len(ins):
+                break
+            nop, nops = ins[k + fwd][1]
+            if fwd == 1 and nop == "s_nop" and nops and int(nops[0]) >= 6:
+                break      # the result's wait states are inside the asm string
+            if nop.startswith("v_mfma") and nops and regs(nops[0]) == dst:
+                break      # the accumulate chain took the result over: a later reader reads THAT MFMA's result
             if not nop.startswith("v_") or nop.startswith("v_mfma"):
                 continue
             rd = set().union(*(regs(o) for o in nops[1:])) if len(nops) > 1 else set()
