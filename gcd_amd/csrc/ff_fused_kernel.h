@@ -109,6 +109,18 @@ constexpr int FF_OFF_B2 = FF_OFF_B1 + 2560 * 4, FF_OFF_LN = FF_OFF_B2 + 320 * 4,
 #ifndef FF_DMA_EVERY
 #define FF_DMA_EVERY 2
 #endif
+// FF_CHAIN_NOP n: wait states carried inside the last MFMA of every GEMM1 accumulator chain (s_nop n; -1: none).  A 4-pass
+// MFMA's result needs 8 before a VALU instruction may read it on gfx950; tools/ff_isa_audit.py rule 3 checks whatever is left.
+#ifndef FF_CHAIN_NOP
+#define FF_CHAIN_NOP 7
+#endif
+#define FF_STR2(x) #x
+#define FF_STR(x) FF_STR2(x)
+#if FF_CHAIN_NOP >= 0
+#define FF_CHAIN_TAIL "\n\ts_nop " FF_STR(FF_CHAIN_NOP)
+#else
+#define FF_CHAIN_TAIL ""
+#endif
 // FF_STAGGER n: workgroup b starts ((b >> 3) & 7) * n * 8128 cycles late (b & 7 is its XCD: neighbours within an XCD are spread) (probe: do the tile-boundary HBM bursts of the CUs coincide?)
 #ifndef FF_STAGGER
 #define FF_STAGGER 0
@@ -567,7 +579,7 @@ __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
               // the LAST MFMA of an accumulator's chain carries the result's wait states inside the string: from here on the
               // value is a finished one for hipcc, whose register allocator may copy it (live-range splitting) in the very
               // next instruction — it did, and read two registers the matrix pipe had not written yet
-              asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\ts_nop 7" : "+v"(aG[rb][tb]) : "v"(a), "v"(X[tb][ks]));
+              asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" FF_CHAIN_TAIL : "+v"(aG[rb][tb]) : "v"(a), "v"(X[tb][ks]));
             } else {
               asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(aG[rb][tb]) : "v"(a), "v"(X[tb][ks]));
             }

@@ -517,6 +517,9 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
   // temporal descriptor must come back as an argument error, never reach a gather
   if (const int rc = validate_geometry(d)) return rc;
 
+  // N == 16: the UNet's output head (320 -> 4, padded).  GCD_TUNE_GEMM_IMPL = 1 keeps it on the general kernel (tests).
+  if (impl == 0 && gcd_conv3x3_narrow_supported(k, d->mode)) return gcd_conv3x3_narrow_launch(k, s);
+
   // split-K: few 256x320 tiles (<= 96 of 256 CUs) and a long K — the 3x3 convs of the 9x16 level
   if (d->workspace && !d->ln_out16 && !d->colstats && !d->a_blocked &&
       d->out_kind != GCD_OUT_GEGLU &&

@@ -98,6 +98,9 @@ int gcd_gemm_pp_launch_splitk(const GemmK& k, int mode, int splitk, float* ws, h
 
 // runtime.hip: tuning knobs (gcd_tune_set / environment), see include/gcd_amd.h
 int gcd_tune_get(int knob);
+// conv_narrow.hip: the 3x3 convolution with N == 16 output columns (the UNet's 320 -> 4 output head)
+bool gcd_conv3x3_narrow_supported(const GemmK& k, int mode);
+int gcd_conv3x3_narrow_launch(const GemmK& k, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // Coalesced epilogue of a wave that owns 64 tokens x 160 channels as acc[5][2] tiles of

@@ -136,6 +136,45 @@ def test_conv3x3_pingpong_full_tiles(gpu, gemm_impl):
         assert e < TOL_F32, f"conv3x3 {H}x{W} s{stride} up{up}: rel-L2 {e:.3e}"
 
 
+@pytest.mark.parametrize("frames,Cin,H,W", [(3, 320, 9, 16), (2, 320, 36, 64), (5, 64, 7, 13), (2, 320, 18, 40)])
+def test_conv3x3_narrow_output_head(gpu, frames, Cin, H, W):
+    """The UNet's output head, Conv2d(C, 4, 3, padding=1) with the four output channels padded to 16 (openaimodel.py
+    `self.out`, video_model.py:455-459): the N == 16 kernel of conv_narrow.hip (weights resident in LDS, patches straight
+    from global memory with range-checked zero padding) against torch's fp32 conv on the same fp16-rounded operands and
+    against the general kernel on the same descriptor; ragged pixel counts (M not a multiple of the 256-pixel task), image
+    borders in every lane position, a scalar output scale."""
+    from gcd_amd import ops, packing
+    g = _gen(31)
+    x = _h(torch.randn(frames, Cin, H, W, generator=g))
+    w = _h(torch.randn(4, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+    b = torch.randn(4, generator=g)
+    ref = F.conv2d(x, w, b, padding=1).permute(0, 2, 3, 1).reshape(frames * H * W, 4)
+    a = x.permute(0, 2, 3, 1).reshape(frames * H * W, Cin).half().to(gpu)
+    wp = packing.pack_conv3x3(w, cout_pad=16).to(gpu)
+    bp = torch.zeros(16)
+    bp[:4] = b
+    M = frames * H * W
+    conv = dict(Cin=Cin, Hi=H, Wi=W, Ho=H, Wo=W, stride=1, upsample=0)
+    out = torch.full((M, 16), float("nan"), device=gpu)
+    ops.gemm(a, wp, out, M=M, mode=ops.GEMM_CONV3X3, bias=bp.to(gpu), conv=conv)
+    torch.cuda.synchronize()
+    e = rel_l2(out[:, :4], ref)
+    assert e < TOL_F32, f"narrow conv {frames}x{H}x{W}, Cin {Cin}: rel-L2 {e:.3e}"
+    assert torch.equal(out[:, 4:], torch.zeros_like(out[:, 4:]))          # padded columns: zero weights, zero bias
+    gen = torch.empty(M, 16, device=gpu)
+    ops.tune_set(ops.TUNE_GEMM_IMPL, 1)
+    try:
+        ops.gemm(a, wp, gen, M=M, mode=ops.GEMM_CONV3X3, bias=bp.to(gpu), conv=conv)
+    finally:
+        ops.tune_set(ops.TUNE_GEMM_IMPL, 0)
+    e2 = rel_l2(out, gen)
+    print(f"narrow conv Cin {Cin} {frames}x{H}x{W}: vs fp32 torch {e:.2e}, vs the general kernel {e2:.2e}")
+    assert e2 < 2e-6
+    ops.gemm(a, wp, gen, M=M, mode=ops.GEMM_CONV3X3, bias=bp.to(gpu), conv=conv, s_acc=0.25)
+    torch.cuda.synchronize()
+    assert rel_l2(gen, 0.25 * out) < 1e-6
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (128, 256, 64), (1000, 64, 640),
                                    (257, 960, 128), (4032, 1280, 1280), (112, 48, 192)])
 def test_gemm_plain_bias_residual(gpu, M, N, K):
