@@ -86,6 +86,96 @@ __global__ __launch_bounds__(256, 2) void linear_smallm_kernel(const float* __re
   }
 }
 
+// The same product for WIDE weights (N >= 4096: the 44 stacked emb_layers of a step are one [~40 000, 1280] fp32 matrix,
+// 205 MB) on the fp32 matrix pipe.  The VALU kernel above re-reads its x operand from LDS once per weight row (128
+// ds_read_b128 per 4 KB of W and wave): 243 us = 0.85 TB/s for that launch.  Here a wave owns 16 weight rows; lane
+// (r, kg) loads W[n0 + r][k + 4 kg .. + 3] (64 contiguous bytes per row and instruction, 128 k in flight per wave
+// under the MFMAs of the previous 128), x comes from LDS once per 16 rows of W, and
+// v_mfma_f32_16x16x4_f32 (fp32 products, fp32 accumulation — the arithmetic of the VALU kernel up to summation order) does
+// 16 x 16 x 4 per instruction: 8 B/clk/SIMD of W at two row blocks of x, above what HBM delivers per CU.
+template <int MB>      // 16-row blocks of x (M <= 16 MB)
+__global__ __launch_bounds__(256, 4) void linear_smallm_mfma_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                    const float* __restrict__ W, const float* __restrict__ b,
+                                                                    float* __restrict__ y, int64_t ldy, int M, int N, int K,
+                                                                    int flags) {
+  __shared__ __attribute__((aligned(16))) float xs[MB * 16 * SM_LDX];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 15, kg = lane >> 4;
+  const int n0 = (blockIdx.x * 4 + wave) * 16;
+  const int n = n0 + r;
+  const float* wrow = W + (int64_t)(n < N ? n : N - 1) * K + 4 * kg;
+  f32x4 acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // W in units of 128 k (8 steps of 16), two register sets: the next unit's loads are issued before this unit's MFMAs
+  // (64 + ~40 registers: four workgroups per CU, so that the ~630 workgroups of the wide launch are all resident at once)
+  f32x4 wa[8], wb[8];
+  auto load_w = [&](int k0, f32x4 (&w)[8]) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int k = k0 + 16 * ks + 4 * kg;
+      w[ks] = k < K ? __builtin_nontemporal_load((const f32x4*)(wrow + k0 + 16 * ks)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto stage_x = [&](int kc) {
+    for (int idx = t; idx < MB * 16 * 64; idx += 256) {
+      const int mm = idx >> 6, kv = (idx & 63) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (mm < M && kc + kv < K) {
+        v = *(const f32x4*)(x + (int64_t)mm * ldx + kc + kv);
+        if (flags & 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+        }
+      }
+      *(f32x4*)(xs + mm * SM_LDX + kv) = v;
+    }
+  };
+  auto compute = [&](int half, const f32x4 (&w)[8]) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const f32x4 xv = *(const f32x4*)(xs + (mb * 16 + r) * SM_LDX + 128 * half + 16 * ks + 4 * kg);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[j], w[ks][j], acc[mb], 0, 0, 0);
+      }
+    }
+  };
+  load_w(0, wa);
+  for (int kc = 0; kc < K; kc += SM_KC) {
+    stage_x(kc);
+    __syncthreads();
+    load_w(kc + 128, wb);      // (beyond K: zeros, no loads)
+    __builtin_amdgcn_sched_barrier(0);
+    compute(0, wa);
+    __builtin_amdgcn_sched_barrier(0);
+    load_w(kc + SM_KC, wa);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1, wb);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  }
+  // accumulator layout: lane (r, kg) holds y[16 mb + 4 kg + e][n0 + r]
+  if (n < N) {
+    const float bn = b ? b[n] : 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = 16 * mb + 4 * kg + e;
+        if (m < M) {
+          float v = acc[mb][e] + bn;
+          if (flags & 2) v = silu_f(v);
+          float* dst = y + (int64_t)m * ldy + n;
+          if (flags & 4) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
 extern "C" int gcd_linear_smallm_f32(const float* x, int64_t ldx, const float* W, const float* b,
                                      float* y, int64_t ldy, int M, int N, int K, int act_flags,
                                      void* stream) {
@@ -102,7 +192,13 @@ extern "C" int gcd_linear_smallm_f32(const float* x, int64_t ldx, const float* W
     const int mc = M - m0 < 32 ? M - m0 : 32;
     const float* xc = x + (int64_t)m0 * ldx;
     float* yc = y + (int64_t)m0 * ldy;
-    if (mc <= 4)
+    if (N >= 4096 && mc > 4) {      // wide weights: the fp32 matrix-pipe kernel streams them at the memory rate
+      const dim3 gridw((N + 63) / 64);
+      if (mc <= 16)
+        hipLaunchKernelGGL(linear_smallm_mfma_kernel<1>, gridw, block, 0, s, xc, ldx, W, b, yc, ldy, mc, N, K, act_flags);
+      else
+        hipLaunchKernelGGL(linear_smallm_mfma_kernel<2>, gridw, block, 0, s, xc, ldx, W, b, yc, ldy, mc, N, K, act_flags);
+    } else if (mc <= 4)
       hipLaunchKernelGGL(linear_smallm_kernel<4>, grid, block, 0, s, xc, ldx, W, b, yc, ldy, mc, N, K, act_flags);
     else if (mc <= 16)
       hipLaunchKernelGGL(linear_smallm_kernel<16>, grid, block, 0, s, xc, ldx, W, b, yc, ldy, mc, N, K, act_flags);

@@ -1050,7 +1050,8 @@ def test_attention_temporal(gpu, clips, T, HW, heads, kernel):
 # ----------------------------------------------------------------------------------- small pieces
 @pytest.mark.parametrize("M,N,K", [(28, 1280, 320), (28, 1280, 1280), (14, 320, 1280), (2, 64, 1024),
                                    (28, 100, 768), (28, 1280, 128), (5, 33, 20), (16, 48, 260),
-                                   (56, 1280, 320), (33, 64, 128), (100, 48, 64)])   # M > 32: two clips under CFG
+                                   (56, 1280, 320), (33, 64, 128), (100, 48, 64),   # M > 32: two clips under CFG
+                                   (28, 4160, 1280), (14, 4101, 260), (40, 8192, 320), (5, 4096, 516)])   # N >= 4096: the fp32 matrix-pipe kernel
 def test_linear_smallm(gpu, M, N, K):
     from gcd_amd import ops
     g = _gen(12)
