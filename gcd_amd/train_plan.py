@@ -1067,6 +1067,17 @@ class TrainPlan:
         self._groups = None
 
 
+_LATE_MARKS = (".emb_layers.", ".attn2.to_v.", ".attn2.to_out.", "time_pos_embed.", "time_embed.", "label_emb.",
+               "mix_factor")
+
+
+def late_parameters(net) -> list:
+    """The parameters whose gradients `_small_backward` finalises after the whole unit walk (three grouped launches for all
+    few-row Linears + one for the mix factors): `training.GradBucketer(..., late=late_parameters(net))` keeps them out of the
+    buckets that can leave during the backward pass."""
+    return [p for n, p in net.named_parameters() if p.requires_grad and any(m in "." + n for m in _LATE_MARKS)]
+
+
 class GraphedPlan:
     """The planned step under two hipGraphs (torch.cuda.graph): after `WARMUP` eager calls with the same signature the
     forward pass is captured, and the backward pass at the first backward after it; later steps copy the inputs into the

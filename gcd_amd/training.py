@@ -511,16 +511,25 @@ class GradBucketer:
     Results equal `allreduce_gradients` (mean over ranks); gloo world-2 test in tests/test_training_host.py."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], dist=None, group=None, bucket_bytes: int = 256 << 20,
-                 unused: Optional[Iterable[torch.nn.Parameter]] = None, static_graph: bool = True):
+                 unused: Optional[Iterable[torch.nn.Parameter]] = None, static_graph: bool = True,
+                 late: Optional[Iterable[torch.nn.Parameter]] = None):
+        """late: parameters whose gradient only becomes final at the very END of the backward pass — with the planned
+        engine the few-row ones (`train_plan.late_parameters(net)`: every ResBlock's emb_layers, attn2.to_v / to_out, the
+        embedding MLPs, time_pos_embed, the mix factors: finalised by three grouped launches after the unit walk).  They
+        sit in nearly every 256 MB bucket of the registration order and would hold every all-reduce back until then; named
+        here they get the LAST bucket(s) to themselves and the others launch while the backward pass still computes."""
         self.dist, self.group = dist, group
         self.active = dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1
         self.world = dist.get_world_size(group) if self.active else 1
-        self.params = [p for p in params if p.requires_grad][::-1]
+        late_ids = {id(p) for p in (late or ())}
+        ordered = [p for p in params if p.requires_grad][::-1]
+        self.params = [p for p in ordered if id(p) not in late_ids] + [p for p in ordered if id(p) in late_ids]
+        n_early = sum(1 for p in ordered if id(p) not in late_ids)
         self.buckets: List[List[torch.nn.Parameter]] = [[]]
         size = 0
-        for p in self.params:
+        for k, p in enumerate(self.params):
             nb = p.numel() * 4
-            if self.buckets[-1] and size + nb > bucket_bytes:
+            if self.buckets[-1] and (size + nb > bucket_bytes or (late_ids and k == n_early)):
                 self.buckets.append([])
                 size = 0
             self.buckets[-1].append(p)

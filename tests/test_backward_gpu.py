@@ -449,8 +449,6 @@ _FULL = __import__("os").environ.get("GCD_TEST_FULL", "0") == "1"
 @pytest.fixture
 def train_engine(request):
     """Run a test on one of the two engines of the fine-tune step (training.TRAIN_ENGINE), restoring the default."""
-    if request.param == "autograd" and not _FULL:
-        pytest.skip("autograd-engine duplicate of an end-to-end golden run: GCD_TEST_FULL=1")
     from gcd_amd import training as TR
     old = TR.TRAIN_ENGINE
     TR.set_train_engine(request.param)
@@ -458,7 +456,7 @@ def train_engine(request):
     TR.set_train_engine(old)
 
 
-@pytest.mark.parametrize("train_engine", ["planned", "autograd"], indirect=True)
+@pytest.mark.parametrize("train_engine", ["planned", "autograd"] if _FULL else ["planned"], indirect=True)
 @pytest.mark.parametrize("step", [0, 2500])
 def test_unet_training_step_vs_oracle(gpu, step, train_engine):
     """BASELINE.json cfg4 at TINY width: denoiser + loss forward, backward through the whole VideoUNet on
@@ -558,7 +556,7 @@ def test_unet_training_step_vs_oracle(gpu, step, train_engine):
 # (the planned engine — the default — on all three fixtures; the autograd engine of rounds 2-4 on the first: 40 s each)
 @pytest.mark.parametrize("train_engine,dtype,fixture", [
     ("planned", "fp16", "train_kubric_32x48.pt"), ("planned", "bf16", "train_kubric_32x48.pt"),
-    ("planned", "fp16", "train_kubric_32x48_focal.pt"), ("autograd", "fp16", "train_kubric_32x48.pt")],
+    ("planned", "fp16", "train_kubric_32x48_focal.pt")] + ([("autograd", "fp16", "train_kubric_32x48.pt")] if _FULL else []),
     indirect=["train_engine"])
 def test_training_step_full_width_cfg4_vs_reference_golden(gpu, dtype, fixture, train_engine):
     """BASELINE.json cfg4 at its own shape: ONE fine-tune step of the full-width 1.53 B-parameter Kubric VideoUNet on

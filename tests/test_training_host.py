@@ -183,6 +183,90 @@ def test_grad_bucketer_overlapped_allreduce_gloo_world2():
     assert gloo_util.run_world(_bucketer_worker, 2) == {0: True, 1: True}
 
 
+def _bucketer_late_worker(rank, world, port, q):
+    """parameters whose gradient is only final at the END of the backward pass (the planned engine's few-row
+    ones) sit in nearly every bucket of the registration order and hold all of them back.  Named as `late` they get the
+    last bucket(s) to themselves: here the biases stand in for them and their gradients are delivered (through the
+    planned engine's listener interface) only after backward() has returned — every bucket without one must already be
+    in flight by then, and the result must still be the mean over ranks."""
+    from gcd_amd.training import GradBucketer, allreduce_gradients
+    gloo_util.init(rank, world, port)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(),
+                                  torch.nn.Linear(64, 4))
+        params = list(net.parameters())
+        late = [p for n, p in net.named_parameters() if n.endswith("bias")]
+        g = torch.Generator().manual_seed(100 + rank)
+        x, y = torch.randn(32, 16, generator=g), torch.randn(32, 4, generator=g)
+        ((net(x) - y) ** 2).mean().backward()
+        allreduce_gradients(params, dist, bucket_bytes=4096)
+        want = [p.grad.clone() for p in params]
+        for p in params:
+            p.grad = None
+        b = GradBucketer(params, dist, bucket_bytes=4096, late=late)
+        n_late_buckets = sum(1 for bk in b.buckets if any(p is q_ for p in bk for q_ in late))
+        ok = all(all(any(p is q_ for q_ in late) for p in bk) or not any(any(p is q_ for q_ in late) for p in bk)
+                 for bk in b.buckets)                      # no bucket mixes the two kinds
+        ok = ok and any(b.buckets[-1][0] is q_ for q_ in late)      # ... and the late ones come last
+        # the weights' gradients arrive from autograd's hooks during backward(); the biases' are held back
+        held = {}
+        for p in late:
+            held[id(p)] = p
+        orig = b._on_grad
+        b._on_grad = lambda p: None if id(p) in held else orig(p)
+        for h in b._hooks:
+            h.remove()
+        b._hooks = [p.register_post_accumulate_grad_hook(b._on_grad) for p in b.params]
+        ((net(x) - y) ** 2).mean().backward()
+        ok = ok and b.launched_during_backward == len(b.buckets) - n_late_buckets      # all the others left already
+        b._on_grad = orig
+        for p in late:                                          # ... what train_plan._small_backward does at the end
+            orig(p)
+        nb = b.finish()
+        ok = ok and nb == len(b.buckets)
+        ok = ok and all(torch.equal(p.grad, w) for p, w in zip(params, want))
+        b.close()
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_bucketer_late_parameters_get_their_own_last_buckets_gloo_world2():
+    assert gloo_util.run_world(_bucketer_late_worker, 2) == {0: True, 1: True}
+
+
+def test_late_parameters_names_the_few_row_parameters():
+    """train_plan.late_parameters: every ResBlock's emb_layers, the one-key cross-attention's to_v / to_out, the embedding
+    MLPs, time_pos_embed and the mix factors — and none of the token-sized contractions."""
+    from gcd_amd import train_plan as TP
+
+    class Blk(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.emb_layers = torch.nn.Sequential(torch.nn.SiLU(), torch.nn.Linear(8, 8))
+            self.in_layers = torch.nn.Sequential(torch.nn.GroupNorm(2, 8), torch.nn.SiLU(), torch.nn.Conv2d(8, 8, 3))
+            self.attn2 = torch.nn.Module()
+            self.attn2.to_q, self.attn2.to_v = torch.nn.Linear(8, 8, bias=False), torch.nn.Linear(8, 8, bias=False)
+            self.attn2.to_out = torch.nn.Sequential(torch.nn.Linear(8, 8))
+            self.attn1 = torch.nn.Module()
+            self.attn1.to_v = torch.nn.Linear(8, 8, bias=False)
+            self.mix_factor = torch.nn.Parameter(torch.zeros(1))
+
+    net = torch.nn.Module()
+    net.time_embed = torch.nn.Sequential(torch.nn.Linear(8, 8))
+    net.label_emb = torch.nn.Sequential(torch.nn.Linear(8, 8))
+    net.aux_label_emb = torch.nn.Sequential(torch.nn.Linear(8, 8))
+    net.blocks = torch.nn.ModuleList([Blk()])
+    net.blocks[0].time_pos_embed = torch.nn.Sequential(torch.nn.Linear(8, 8))
+    names = {n for n, p in net.named_parameters() if any(p is q_ for q_ in TP.late_parameters(net))}
+    assert names == {"time_embed.0.weight", "time_embed.0.bias", "label_emb.0.weight", "label_emb.0.bias",
+                     "aux_label_emb.0.weight", "aux_label_emb.0.bias", "blocks.0.emb_layers.1.weight",
+                     "blocks.0.emb_layers.1.bias", "blocks.0.attn2.to_v.weight", "blocks.0.attn2.to_out.0.weight",
+                     "blocks.0.attn2.to_out.0.bias", "blocks.0.mix_factor", "blocks.0.time_pos_embed.0.weight",
+                     "blocks.0.time_pos_embed.0.bias"}
+
+
 def _bucketer_unused_worker(rank, world, port, q):
     """(a) unreached parameters inside EVERY bucket (the attn2.to_q / to_k / norm2 pattern of the VideoUNet)
     must not push the launches into finish(): named up front, or learned from the first pass, every bucket launches

@@ -67,7 +67,9 @@ def main():
         # the parameters behind the one-key cross-attentions are never reached by the graph: named
         # up front, every bucket launches during the FIRST backward pass already
         dead = [p for n, p in net.named_parameters() if ".attn2.to_q." in n or ".attn2.to_k." in n or ".norm2." in n]
-        bucketer = TR.GradBucketer(net.parameters(), dist, unused=dead)
+        from gcd_amd import train_plan as TP
+        late = TP.late_parameters(net) if TR.TRAIN_ENGINE == "planned" else None
+        bucketer = TR.GradBucketer(net.parameters(), dist, unused=dead, late=late)
     g = torch.Generator(device=dev).manual_seed(1)
     x0 = torch.randn(BT, 4, h, w, generator=g, device=dev)
     cond = {"crossattn": torch.randn(BT, 1, 1024, generator=g, device=dev),
