@@ -3,7 +3,7 @@
 // leaves the CU.  Reference: sgm/modules/attention.py:87-121 (GEGLU, FeedForward), video_attention.py:109-140 (ff_in / ff of
 // the temporal block and their residuals), util.py:364-368 (AlphaBlender on the last one).
 //
-// Shape of the work (round 6; DESIGN.md section 3.10): 4 waves = ONE wave per SIMD, 512 registers each.  A wave owns T
+// Shape of the work (round 6; DESIGN.md section 3.3): 4 waves = ONE wave per SIMD, 512 registers each.  A wave owns T
 // blocks of 16 tokens across the FULL output width, so nothing is exchanged between waves; they only share the weight
 // stream in LDS.  Per wave:
 //   X        T x 10 B-fragments (16 tokens x 32 channels each) held in VGPRs for the whole tile,

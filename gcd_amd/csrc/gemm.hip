@@ -479,7 +479,7 @@ extern "C" int gcd_gemm_f16(const gcd_gemm_desc* d, void* stream) {
   }
 #ifndef GCD_ABLATION_BUILD
   // Round 5: the fused LayerNorm in the producer's epilogue and the tile-blocked GEGLU hidden layout were built, are
-  // bit-correct, and measured slower / neutral (DESIGN.md section 7): they live in the ablation build
+  // bit-correct, and measured slower / neutral (DESIGN.md section 3.2): they live in the ablation build
   // (python -m gcd_amd.csrc.build --ablation), not in the product library.
   GCD_CHECK_ARG(!d->ln_out16 && !d->out_blocked && !d->a_blocked,
                 "gcd_gemm_f16: ln_out16 / out_blocked / a_blocked are compiled into the ablation build only");

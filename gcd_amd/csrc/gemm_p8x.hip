@@ -1,4 +1,4 @@
-// gemm_p8x.hip — the tile epilogue under the NEXT tile's K loop (round 4; VERDICT r3 item 2, DESIGN.md §7).
+// gemm_p8x.hip — the tile epilogue under the NEXT tile's K loop (round 4; VERDICT r3 item 2, DESIGN.md §3.2).
 //
 // gemm_p8.hip runs K loop -> epilogue -> K loop in series: its 160 accumulator registers leave no room for a second
 // tile.  Measured split of its fp16-output shapes (profiles/r04e_p8_ablations.txt, us): L0 GEGLU 597 = K loop 349 +
@@ -6,7 +6,7 @@
 // evaluates GELUs its matrix pipe idles.  Here a workgroup owns 256 x 160 tiles and every wave TWO accumulator sets of
 // 80 registers (its 64 x 80 wave tile as 5 x 4 blocks of v_mfma_f32_16x16x32_f16): `acc` takes tile i+1's K loop while
 // `prev` — tile i — is finished in ten slices issued INSIDE the MFMA clusters of tile i+1's first ten phases (a wave's
-// own VALU / LDS / store instructions issue in the shadow of its own MFMAs: issue rule (i) of DESIGN.md §3.2).
+// own VALU / LDS / store instructions issue in the shadow of its own MFMAs: the issue rule of DESIGN.md §3.3).
 // The persistent workgroup sees ONE stream of 32-deep sub-tiles across all its tiles: no per-tile prologue, no drain.
 //
 // Scope: GCD_GEMM_PLAIN, more tiles than CUs (persistent), M %% 256 == 0, N %% 160 == 0, K / 32 == 10 or >= 12,

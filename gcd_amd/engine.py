@@ -481,7 +481,7 @@ class UNetEngine:
         ws = self.ws
         hid = ws.alloc((M, F["w1"].shape[0] // 2), torch.float16)
         # the hidden tensor only lives between these two GEMMs: where both run on the ping-pong kernel it
-        # is kept tile-blocked ([M/256][N/320][256][160]: whole 128-byte lines per store, §7 of DESIGN.md)
+        # is kept tile-blocked ([M/256][N/320][256][160]: whole 128-byte lines per store, §3.2 of DESIGN.md)
         blocked = epi.get("ln") is None and ops.gemm_hidden_blocked_ok(M, F["w1"].shape[0], F["w2"].shape[0])
         self._gemm(a16, F["w1"], hid, M=M, bias=F["b1"], out_kind=OUT_GEGLU, out_blocked=blocked)
         ws.release(a16)

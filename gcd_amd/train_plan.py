@@ -191,13 +191,28 @@ class _SmallGroup:
             return self._tabs[key]
         # the device table of this (stage, mode) from the previous step, when every pointer in it is unchanged: the few-row
         # tensors live in the plan's persistent buffers and arenas, whose bump allocation is deterministic
-        sig = (mode, plan.accumulate if mode == "wgrad" else False) + tuple(
-            (it["x"].data_ptr(), it["y"].data_ptr(), 0 if it.get("dy") is None else it["dy"].data_ptr(),
-             0 if it["dx"] is None else it["dx"].data_ptr()) for it in self.items)
+        # (everything a table entry is made of: operand / weight / bias / gradient-destination pointers, shapes, strides and
+        #  flags — a table that is served from the cache must be the table that would be built)
+        def _ptr(t):
+            return 0 if t is None else t.data_ptr()
+        wg = mode == "wgrad"
+        sig = (mode, plan.accumulate if wg else False) + tuple(
+            (_ptr(it["x"]), _ptr(it["y"]), _ptr(it.get("dy")), _ptr(it["dx"]), _ptr(it["w"]), _ptr(it["b"]),
+             tuple(it["x"].shape), it["x"].stride(0), it["y"].stride(0), it["w"].shape[0],
+             0 if it.get("dy") is None else it["dy"].stride(0), 0 if it["dx"] is None else it["dx"].stride(0),
+             it["silu"], it["acc"], it["dx_silu"], it["w"].requires_grad, it["b"] is not None and it["b"].requires_grad,
+             _ptr(plan.grad_dest(it["w"])) if wg and it["w"].requires_grad else 0,
+             _ptr(plan.grad_dest(it["b"])) if wg and it["b"] is not None and it["b"].requires_grad else 0)
+            for it in self.items)
         hit = plan._table_cache.get((self.name, mode))
         if hit is not None and hit[0] == sig:
             self._tabs[key] = hit[1]
             return hit[1]
+        # a rebuild copies a host table to the device: not something a stream capture can hold (the host buffer is gone at
+        # replay).  GraphedPlan captures only after warm-up steps with the same signature, which leave every table cached.
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(f"train_plan: the few-row problem table {self.name}/{mode} would be rebuilt inside a stream "
+                               "capture (its pointers, shapes or flags differ from the warm-up steps)")
         probs, block0 = [], 0
         for it in self.items:
             x, w, y = it["x"], it["w"], it["y"]

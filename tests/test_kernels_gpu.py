@@ -484,7 +484,7 @@ def test_feedforward_tile_blocked_hidden(gpu, gemm_impl):
     b2 = torch.randn(C, generator=g).to(gpu)
     r1 = torch.randn(M, C, generator=g).to(gpu)
     ok = ops.gemm_hidden_blocked_ok(M, 2 * H, C, enabled=True)
-    # Round 5: the blocked hidden layout (measured neutral, DESIGN.md section 7) is compiled into the ABLATION build only
+    # Round 5: the blocked hidden layout (measured neutral, DESIGN.md section 3.2) is compiled into the ABLATION build only
     # (tools/libgcd_amd_ablate.so through GCD_AMD_LIB): the product library answers "no" and refuses the descriptors.
     import os
     ablation = "ablate" in os.environ.get("GCD_AMD_LIB", "")

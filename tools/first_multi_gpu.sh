@@ -6,7 +6,10 @@
 #                                  ones over the nccl backend returns N (`rccl_ranks`) — the scaling curve of cfg2
 #   2. tests/test_parallel_gpu.py  with GCD_DIST_BACKEND=nccl and one GPU per rank (GCD_TEST_GPUS_PER_RANK=1): clip
 #                                  sharding through the fused hipGraph loop, the data-parallel fine-tune step
-#   3. tools/train_step_bench.py   under torchrun, GradBucketer on RCCL: step time, exposed all-reduce ms (cfg4's DDP)
+#   3. bench.py --train            the fine-tune step of cfg4 on ONE GPU of the node (bf16 + fp16, parity beside it): the
+#                                  single-GPU figure the DDP step below is compared with
+#   4. tools/train_step_bench.py   under torchrun, GradBucketer on RCCL (few-row parameters in their own last buckets):
+#                                  step time, exposed all-reduce ms (cfg4's DDP)
 # Reference pattern: scripts/test.py:1051-1090 (one replica per GPU, strided clips), main.py:826-843 (DDPStrategy).
 set -u
 N=${1:-8}
@@ -34,6 +37,16 @@ except Exception as e:
 PY
 done
 GCD_DIST_BACKEND=nccl GCD_TEST_GPUS_PER_RANK=1 python -m pytest tests/test_parallel_gpu.py -x -q -m gpu 2>&1 | tail -5 | tee $OUT/test_parallel_gpu_nccl.log
+python bench.py --train > $OUT/bench_train.json 2> $OUT/bench_train.err || { echo "bench --train FAILED" | tee -a $OUT/summary.txt; rc=1; }
+python - $OUT/bench_train.json <<'PY' | tee -a $OUT/summary.txt
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    t = d["train"]
+    print("fine-tune step, 1 GPU: " + ", ".join(f"{k} {v['step_s']:.4f} s = {v['tflops']:.0f} TFLOP/s" for k, v in t.items()))
+except Exception as e:
+    print(f"no bench --train line ({e})")
+PY
 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29641 \
   tools/train_step_bench.py --steps 5 --ddp > $OUT/train_step_ddp.json 2> $OUT/train_step_ddp.err || { echo "DDP train step FAILED" | tee -a $OUT/summary.txt; rc=1; }
 tail -2 $OUT/train_step_ddp.json | tee -a $OUT/summary.txt

@@ -64,7 +64,7 @@ def main():
     opt = TR.AdamHIP(net.parameters(), lr=2e-5)
     bucketer = None
     if dist is not None:
-        # the parameters behind the one-key cross-attentions are never reached by the graph (DESIGN.md §3.3): named
+        # the parameters behind the one-key cross-attentions are never reached by the graph (DESIGN.md §3.6): named
         # up front, every bucket launches during the FIRST backward pass already
         dead = [p for n, p in net.named_parameters() if ".attn2.to_q." in n or ".attn2.to_k." in n or ".norm2." in n]
         from gcd_amd import train_plan as TP
