@@ -109,6 +109,13 @@ constexpr int FF_OFF_B2 = FF_OFF_B1 + 2560 * 4, FF_OFF_LN = FF_OFF_B2 + 320 * 4,
 #ifndef FF_DMA_EVERY
 #define FF_DMA_EVERY 2
 #endif
+// FF_ZPRE: LayerNorm form, 1 = the next tile's residual rows are requested during this tile's last iteration where no second
+// residual stream needs the registers (EPI 0), 2 = in every form, 0 = at the tile's top (the default: measured NEUTRAL, 718-734
+// us either way at M = 258 048 — the loads then share the CU's memory pipe with the stores of the same iteration, and that
+// iteration has only 40 MFMAs to hide anything under: the boundary's memory time is a sum of bytes, not of phases)
+#ifndef FF_ZPRE
+#define FF_ZPRE 0
+#endif
 // FF_CHAIN_NOP n: wait states carried inside the last MFMA of every GEMM1 accumulator chain (s_nop n; -1: none).  A 4-pass
 // MFMA's result needs 8 before a VALU instruction may read it on gfx950; tools/ff_isa_audit.py rule 3 checks whatever is left.
 #ifndef FF_CHAIN_NOP
@@ -260,6 +267,26 @@ __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
                    "+v"(X[tb][6]), "+v"(X[tb][7]), "+v"(X[tb][8]), "+v"(X[tb][9]));
   };
   if constexpr (!LN) pin_x();
+  // LayerNorm form: z = the fp32 residual rows of a tile in the ACCUMULATOR layout (lane (r, g): token r, channels 16 cb + 4 g
+  // .. + 3 of every block cb).  With FF_ZPRE the NEXT tile's z is requested at the start of this tile's last iteration — the
+  // GELU state, the GEMM1 accumulators and the fragment batches are dead there: 160 registers are free — so that its 164 KB
+  // per CU travel under that iteration's MFMAs and stores instead of alone at the tile's top.
+  constexpr bool ZPRE = LN && FF_ZPRE != 0 && (FF_ZPRE == 2 || !has2);
+  f32x4 zn[LN ? T : 1][LN ? 20 : 1];
+  auto load_z = [&](int m0) {
+    if constexpr (LN) {
+#pragma unroll
+      for (int tb = 0; tb < T; ++tb) {
+        const float* src = p.x32 + (int64_t)min(m0 + 16 * tb + r, p.M - 1) * p.ldx32 + 4 * g;
+#pragma unroll
+        for (int cb = 0; cb < 20; ++cb) zn[tb][cb] = *(const f32x4*)(src + 16 * cb);
+      }
+      asm volatile("" ::: "memory");      // (requested HERE: the loads may not sink below the MFMAs that follow)
+    }
+  };
+  if constexpr (ZPRE) {
+    if ((int)blockIdx.x < ntiles) load_z(tile_of(blockIdx.x) * TILE + wave * (16 * T));
+  }
 
   for (int tile0 = blockIdx.x; tile0 < ntiles; tile0 += gridDim.x) {
     const int m_base = tile_of(tile0) * TILE + wave * (16 * T);
@@ -272,13 +299,12 @@ __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
       // the residual the accumulators start from and, normalised (two-pass statistics over the 320 channels of a token =
       // the 80 values of a lane + the lanes r + 16, r + 32, r + 48; the formula of norm.hip's layernorm16_kernel) and rounded
       // to fp16, GEMM1's B fragments — the packer's K order (kperm) makes k-step ks of a lane exactly blocks 2 ks, 2 ks + 1.
+      if constexpr (!ZPRE) load_z(m_base);
       f32x4 z[T][20];
 #pragma unroll
-      for (int tb = 0; tb < T; ++tb) {
-        const float* src = p.x32 + (int64_t)min(m_base + 16 * tb + r, p.M - 1) * p.ldx32 + 4 * g;
+      for (int tb = 0; tb < T; ++tb)
 #pragma unroll
-        for (int cb = 0; cb < 20; ++cb) z[tb][cb] = *(const f32x4*)(src + 16 * cb);
-      }
+        for (int cb = 0; cb < 20; ++cb) z[tb][cb] = zn[tb][cb];
       if (p.addvec) {
         const float* av = p.addvec + (int64_t)(min(m_base, p.M - 1) / p.rows_per_vec) * p.ld_addvec + 4 * g;
 #pragma unroll
@@ -498,6 +524,7 @@ __global__ __launch_bounds__(256) void FF_KERNEL(const FfK p) {
           }
           if constexpr (!LN) load_x(Xn, m_next);
         }
+        if constexpr (ZPRE) load_z(m_next);      // (unconditional: the last tile re-reads its own rows; no branch around loads)
         if constexpr (has2) {
           ff_static_for<0, 6>([&](auto Cb) { fetch_r2(decltype(Cb)::value); });
         }
