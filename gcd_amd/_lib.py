@@ -15,7 +15,7 @@ _PKG = Path(__file__).resolve().parent
 # tools; the product is the in-tree library next to this file.
 LIB_PATH = Path(os.environ["GCD_AMD_LIB"]).resolve() if os.environ.get("GCD_AMD_LIB") else _PKG / "libgcd_amd.so"
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # GEMM modes / output kinds (mirror include/gcd_amd.h)
 GEMM_PLAIN, GEMM_CONV3X3, GEMM_TEMPORAL3 = 0, 1, 2
@@ -79,6 +79,10 @@ SIGNATURES = {
     "gcd_ff_pack_f16": (_i, [_vp, _vp, _vp, _i, _vp]),
     "gcd_ff_fused_supported": (_i, [_i, _i, _i]),
     "gcd_ff_fused_f16": (_i, [C.POINTER(FfDesc), _vp]),
+    "gcd_lnqkv_packed_bytes": (_i64, [_i]),
+    "gcd_lnqkv_supported": (_i, [_i, _i]),
+    "gcd_lnqkv_pack_f16": (_i, [_vp, _i, _vp, _vp]),
+    "gcd_lnqkv_f16": (_i, [_vp, _i64, _vp, _vp, _f, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "gcd_groupnorm_stats_from_colsums": (_i, [_vp, _i, _vp, _i, _i64, _i64, _f, _vp, _vp]),
     "gcd_linear_smallm_f32": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "gcd_groupnorm_stats": (_i, [_vp, _i64, _i, _vp, _i64, _i, _i64, _i64, _f, _vp, _i, _vp, _vp]),

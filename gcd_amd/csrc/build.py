@@ -18,7 +18,7 @@ PKG = CSRC.parent
 ROOT = PKG.parent
 LIB = PKG / "libgcd_amd.so"
 STAMP = PKG / ".libgcd_amd.stamp"
-SOURCES = ["runtime.hip", "gemm.hip", "gemm_pp.hip", "gemm_p8.hip", "conv_narrow.hip", "ff_fused.hip", "norm.hip", "attention.hip",
+SOURCES = ["runtime.hip", "gemm.hip", "gemm_pp.hip", "gemm_p8.hip", "conv_narrow.hip", "ff_fused.hip", "lnqkv.hip", "norm.hip", "attention.hip",
            "attn_bwd.hip", "elementwise.hip", "backward.hip"]
 # per-source extra flags.  ff_fused.hip: hipcc's SLP pass pairs the GELU polynomial's scalar FMAs into v_pk_fma_f32, which
 # does not issue in the shadow of an MFMA (tools/issue_probe; the kernel places every one of them behind an MFMA by hand)

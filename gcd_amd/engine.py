@@ -246,9 +246,13 @@ class UNetEngine:
             return d
 
         def pack_attn(att, q_scale=1.0):
-            return dict(wqkv=packing.pack_qkv(att.to_q.weight, att.to_k.weight, att.to_v.weight,
-                                              q_scale=q_scale),
-                        wo=packing.pack_linear(att.to_out[0].weight), bo=_f32(att.to_out[0].bias))
+            d = dict(wqkv=packing.pack_qkv(att.to_q.weight, att.to_k.weight, att.to_v.weight,
+                                           q_scale=q_scale),
+                     wo=packing.pack_linear(att.to_out[0].weight), bo=_f32(att.to_out[0].bias))
+            if d["wqkv"].is_cuda and tuple(d["wqkv"].shape) == (960, 320):
+                # the one-kernel LayerNorm + q | k | v's fragment-order weights (lnqkv.hip)
+                d["wqkv_p"] = ops.lnqkv_pack(d["wqkv"])
+            return d
 
         def pack_tr(tr: SpatialVideoTransformer):
             d = dict(kind="attn", C=tr.in_channels, heads=tr.heads, depth=tr.depth)
@@ -477,6 +481,21 @@ class UNetEngine:
         ops.ff_fused(x32, F["wp"], F["b1"], F["b2"], out, M=M, **kw)
         return True
 
+    def _ln_qkv(self, A, x32, affine, M) -> torch.Tensor:
+        """q | k | v = to_qkv(norm1(x32)) as fp16 [M, 3 C]: ONE launch where the model width is 320 and the tile count pays
+        (lnqkv.hip: the fp32 rows are read once, the normalised operand never reaches memory), else LayerNorm + GEMM."""
+        ws = self.ws
+        N3 = A["wqkv"].shape[0]
+        qkv = ws.alloc((M, N3), torch.float16)
+        if "wqkv_p" in A and not self.fuse_layernorm and ops.lnqkv_ok(M, A["wqkv"].shape[1], N3):
+            sched = self._next_dir() if _ZIGZAG in (1, 2) else 0
+            ops.lnqkv(x32, affine[0], affine[1], A["wqkv_p"], qkv, M=M, N=N3, sched=sched)
+            return qkv
+        a16 = self._ln(x32, affine)
+        self._gemm(a16, A["wqkv"], qkv, M=M, out_kind=OUT_F16)
+        ws.release(a16)
+        return qkv
+
     def _ff(self, F, a16, M, **epi):
         ws = self.ws
         hid = ws.alloc((M, F["w1"].shape[0] // 2), torch.float16)
@@ -516,10 +535,12 @@ class UNetEngine:
         last = None
         for bi, (sb, tb) in enumerate(blocks):
             # ---- spatial BasicTransformerBlock (attention.py:551-572) ----
-            a16 = nxt if fuse else self._ln(xs, sb["ln1"])
-            qkv = ws.alloc((M, 3 * Cc), torch.float16)
-            self._gemm(a16, sb["attn"]["wqkv"], qkv, M=M, out_kind=OUT_F16)
-            ws.release(a16)
+            if fuse:
+                qkv = ws.alloc((M, 3 * Cc), torch.float16)
+                self._gemm(nxt, sb["attn"]["wqkv"], qkv, M=M, out_kind=OUT_F16)
+                ws.release(nxt)
+            else:
+                qkv = self._ln_qkv(sb["attn"], xs, sb["ln1"], M)
             vt = ws.alloc((N * heads * 64 * S_pad,), torch.float16)
             ops.attn_transpose_v(qkv, N, HW, heads, vt, S_pad)
             ao = ws.alloc((M, Cc), torch.float16)
@@ -542,10 +563,12 @@ class UNetEngine:
                 a16 = nxt if fuse else self._ln(xs, tb["ln_in"], addvec=pos, rows_per_vec=HW, sum_out=xm)
                 nxt, req = ln_req(tb["ln1"])
                 self._ff(tb["ff_in"], a16, M, out=xm, r1=xm, ln=req)
-            a16 = nxt if fuse else self._ln(xm, tb["ln1"])
-            qkv = ws.alloc((M, 3 * Cc), torch.float16)
-            self._gemm(a16, tb["attn"]["wqkv"], qkv, M=M, out_kind=OUT_F16)
-            ws.release(a16)
+            if fuse:
+                qkv = ws.alloc((M, 3 * Cc), torch.float16)
+                self._gemm(nxt, tb["attn"]["wqkv"], qkv, M=M, out_kind=OUT_F16)
+                ws.release(nxt)
+            else:
+                qkv = self._ln_qkv(tb["attn"], xm, tb["ln1"], M)
             ao = ws.alloc((M, Cc), torch.float16)
             ops.attn_temporal(qkv, ao, N // T, T, HW, heads)
             self._walked(0)

@@ -265,6 +265,39 @@ def ff_fused(x: torch.Tensor, wp: torch.Tensor, b1: torch.Tensor, b2: torch.Tens
     return out
 
 
+# ---- LayerNorm + q | k | v as one kernel (gcd_lnqkv_f16; model width 320) ------------------------------------------------
+# GCD_LNQKV=0 keeps LayerNorm + GEMM everywhere (A/B).  256-token tiles on a persistent grid: used from 2 rounds of tiles.
+_LNQKV_ON = os.environ.get("GCD_LNQKV", "1") != "0"
+LNQKV_MIN_TOKENS = int(os.environ.get("GCD_LNQKV_MIN_TOKENS", str(2 * 256 * 256)))
+
+
+def lnqkv_ok(M: int, C_: int, N: int, enabled: Optional[bool] = None) -> bool:
+    on = _LNQKV_ON if enabled is None else enabled
+    return bool(on and M >= LNQKV_MIN_TOKENS and _lib.load().gcd_lnqkv_supported(C_, N))
+
+
+def lnqkv_pack(w16: torch.Tensor) -> torch.Tensor:
+    """The fragment-order image of a [N, 320] fp16 projection weight (gcd_lnqkv_pack_f16).  Once per parameter version."""
+    _need_gpu(w16)
+    assert w16.dtype == torch.float16 and w16.is_contiguous() and w16.shape[1] == 320 and w16.shape[0] % 64 == 0
+    lib = _lib.load()
+    wp = torch.empty(int(lib.gcd_lnqkv_packed_bytes(w16.shape[0])) // 2, device=w16.device, dtype=torch.float16)
+    check(lib.gcd_lnqkv_pack_f16(w16.data_ptr(), w16.shape[0], wp.data_ptr(), _stream()), "gcd_lnqkv_pack_f16")
+    return wp
+
+
+def lnqkv(x32: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, wp: torch.Tensor, out16: torch.Tensor, *, M: int, N: int,
+          eps: float = 1e-5, sched: int = 0):
+    """out16[M, N] = LN(x32[M, 320]) @ W^T in one kernel (wp = lnqkv_pack(W))."""
+    _need_gpu(x32, gamma, beta, wp, out16)
+    assert x32.dtype == torch.float32 and out16.dtype == torch.float16
+    with _Timed("gemm", 2.0 * M * 320 * N, M=M, N=N, K=320, mode=GEMM_PLAIN, out_kind=OUT_F16, nres=0, cin=320, stride=1,
+                up=0, fused_ln=1):
+        check(_lib.load().gcd_lnqkv_f16(x32.data_ptr(), _ld(x32), gamma.data_ptr(), beta.data_ptr(), eps, wp.data_ptr(),
+                                        out16.data_ptr(), _ld(out16), M, 320, N, int(sched), _stream()), "gcd_lnqkv_f16")
+    return out16
+
+
 # Tile-blocked GEGLU hidden tensor: implemented and bit-identical, but measured neutral in the full step
 # (112.4-112.6 ms off vs 112.5-112.8 ms on, interleaved runs; tools/store_probe.cpp's 25 % store penalty
 # for 320-byte segments does not surface inside the GEGLU GEMM), so it is off unless GCD_HIDDEN_BLOCKED=1.

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GCD_AMD_ABI_VERSION 8
+#define GCD_AMD_ABI_VERSION 9
 
 /* ---- library ------------------------------------------------------------------------------ */
 int gcd_abi_version(void);
@@ -237,6 +237,20 @@ int64_t gcd_ff_packed_bytes(void);
 int gcd_ff_pack_f16(const void* w1, const void* w2, void* wp, int for_ln, void* stream);
 int gcd_ff_fused_supported(int M, int C, int hidden);
 int gcd_ff_fused_f16(const gcd_ff_desc* desc, void* stream);
+
+/* ---- LayerNorm + q | k | v projection as one launch where the model width is 320 (ABI v9) ------------------------------
+ * out16[M, N] (fp16) = LN(x32[M, 320]; gamma, beta, eps) @ W[N, 320]^T: `self.attn1(self.norm1(x), ...)`'s to_q | to_k | to_v
+ * of attention.py:519-521 / 300-316 and video_attention.py:90-93 (no bias; the softmax scale is folded into the q rows of
+ * W by the caller, as for gcd_gemm_f16).  Replaces gcd_layernorm_f16 + gcd_gemm_f16(GCD_OUT_F16) with the same rounding
+ * points (LayerNorm output to fp16, fp32 accumulation, one fp16 rounding of the result); the fp32 rows are read once and
+ * the normalised operand never reaches memory.  wp = gcd_lnqkv_pack_f16(W) (gcd_lnqkv_packed_bytes(N) bytes), once per
+ * parameter version: W in MFMA-fragment order per chunk of 64 output features.  N % 64 == 0.  sched bit 0: walk the
+ * 256-token tiles from the end (pure scheduling, as gcd_gemm_desc.sched).                                                  */
+int64_t gcd_lnqkv_packed_bytes(int N);
+int gcd_lnqkv_supported(int C, int N);
+int gcd_lnqkv_pack_f16(const void* W, int N, void* wp, void* stream);
+int gcd_lnqkv_f16(const float* x32, int64_t ldx32, const float* gamma, const float* beta, float eps, const void* wp,
+                  void* out16, int64_t ldo, int M, int C, int N, int sched, void* stream);
 
 /* y[M,N] (fp32) = [y +] act_out( act_in(x[M,K]) @ W[N,K]^T + b ), fp32 weights, any M >= 1 (rows are processed 32 at a time).
  * act flags: bit0 = SiLU on input, bit1 = SiLU on output, bit2 = accumulate into y.

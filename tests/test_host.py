@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()                       # raises if the .so has not been built
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.gcd_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.gcd_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_train_library_exports_every_declared_symbol():

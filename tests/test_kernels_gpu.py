@@ -388,6 +388,45 @@ def test_ff_fused_one_kernel(gpu, M, form):
         assert torch.equal(inpl, out)
 
 
+@pytest.mark.parametrize("M,ld", [(256 * 70 + 77, 320), (9216 * 3, 320), (5, 320), (1000, 384)])
+def test_layernorm_qkv_one_kernel(gpu, M, ld):
+    """q | k | v = to_qkv(norm1(x)) (attention.py:519-521 with attention.py:300-316; video_attention.py:90-93) as ONE launch
+    from the fp32 residual stream at model width 320 (lnqkv.hip): against fp32 torch with the LayerNorm output rounded to
+    fp16 where the HIP paths round it, and against the two launches it replaces (gcd_layernorm_f16 + gcd_gemm_f16 with an
+    fp16 output) — same rounding points, so the two HIP results differ by fp32 summation order and a handful of fp16
+    roundings that fall the other way; ragged token counts, a padded row stride, both walk directions bit-identical."""
+    from gcd_amd import ops
+    g = _gen(77)
+    C, N = 320, 960
+    x = torch.randn(M, C, generator=g) * 1.3 + 0.4
+    w = _h(torch.randn(N, C, generator=g) / math.sqrt(C))
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g) * 0.5
+    ref = _h(F.layer_norm(x, (C,), gamma, beta, 1e-5)) @ w.t()
+    xg = torch.zeros(M, ld, device=gpu)
+    xg[:, :C] = x.to(gpu)
+    xv = xg[:, :C]
+    w16 = w.half().to(gpu)
+    wp = ops.lnqkv_pack(w16)
+    gg, bg = gamma.to(gpu), beta.to(gpu)
+    out = torch.full((M, N), float("nan"), device=gpu, dtype=torch.float16)
+    ops.lnqkv(xv, gg, bg, wp, out, M=M, N=N)
+    torch.cuda.synchronize()
+    e = rel_l2(out.float(), ref)
+    assert e < TOL_F16, f"LayerNorm + q|k|v in one launch, M = {M}: rel-L2 {e:.3e}"
+    x16 = torch.empty(M, C, device=gpu, dtype=torch.float16)
+    ops.layernorm(xv, gg, bg, x16)
+    two = torch.empty(M, N, device=gpu, dtype=torch.float16)
+    ops.gemm(x16, w16, two, M=M, out_kind=ops.OUT_F16)
+    torch.cuda.synchronize()
+    e2 = rel_l2(out.float(), two.float())
+    print(f"LayerNorm + q|k|v in one launch, M = {M}: vs fp32 torch {e:.2e}, vs LayerNorm kernel + GEMM {e2:.2e}")
+    assert e2 < 3e-4
+    rev = torch.empty_like(out)
+    ops.lnqkv(xv, gg, bg, wp, rev, M=M, N=N, sched=1)
+    torch.cuda.synchronize()
+    assert torch.equal(rev, out)
+
+
 @pytest.mark.parametrize("M,form", [(128 * 256 + 77, "plain"), (9216 * 3, "pos"), (9216 * 2, "blend16"), (5, "plain")])
 def test_ff_fused_with_its_layernorm(gpu, M, form):
     """The form the engine uses: x = ff(norm(x + pos)) + (x + pos) [AlphaBlender with a second stream] as ONE launch from the
