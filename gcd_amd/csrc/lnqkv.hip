@@ -18,13 +18,17 @@
 //     consecutive features: one 16-byte store, four lanes = 64 contiguous bytes per token;
 //   * 8 waves = 2 per SIMD (32 accumulator + 80 operand registers): one wave's loads, statistics and stores run under the
 //     other's MFMAs.  MFMAs are compiler builtins here (hipcc pads their hazards).
+// Forms measured (tools/lnqkv_bench.py, cold caches, M = 258 048): 8 waves x 32 tokens 271-278 us (the default; 222 us inside
+// the sampler step, where the rows were just written); with a chunk's stores under the next chunk's MFMAs (second accumulator
+// set) 264-275; 4 waves x 64 tokens (one wave per SIMD, half the LDS fragment reads per MFMA) 297-306 — LDS is not what it
+// waits for.  GCD_LNQKV_FORM selects them (development).
 // Rounding points are those of the two launches it replaces: LayerNorm output to fp16, fp32 accumulation, q | k | v to fp16.
 #include "common.h"
 
 namespace {
 
 constexpr int LQ_C = 320, LQ_CHUNK = 64, LQ_CHUNK_BYTES = LQ_CHUNK * LQ_C * 2;      // 40 960
-constexpr int LQ_WAVES = 8, LQ_T = 2, LQ_TILE = LQ_WAVES * LQ_T * 16;                // 256 tokens per workgroup tile
+constexpr int LQ_TILE = 256;      // tokens per workgroup tile = waves x token blocks of 16 per wave
 constexpr int LQ_OFF_LN = 2 * LQ_CHUNK_BYTES, LQ_SMEM = LQ_OFF_LN + 2 * LQ_C * 4;    // 84 480 B
 
 struct LnQkvK {
@@ -53,8 +57,10 @@ __device__ __forceinline__ float lq_sum_lane_bits_45(float a) {
   return a;
 }
 
-template <bool PIPE>
+template <int LQ_WAVES, int LQ_T, bool PIPE>
 __global__ __launch_bounds__(LQ_WAVES * 64) void lnqkv_kernel(const LnQkvK p) {
+  static_assert(LQ_WAVES * LQ_T * 16 == LQ_TILE && 40 % LQ_WAVES == 0, "tile shape");
+  constexpr int NP = 40 / LQ_WAVES;      // DMA pieces per wave and chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);      // (scalar: DMA operands are SGPRs)
   const int r = lane & 15, g = lane >> 4;
@@ -62,12 +68,12 @@ __global__ __launch_bounds__(LQ_WAVES * 64) void lnqkv_kernel(const LnQkvK p) {
   for (int i = t; i < 2 * LQ_C; i += LQ_WAVES * 64) ((float*)(smem + LQ_OFF_LN))[i] = i < LQ_C ? p.gamma[i] : p.beta[i - LQ_C];
   const __amdgpu_buffer_rsrc_t rsrcW =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, p.nchunks * LQ_CHUNK_BYTES, 0x00020000);
-  // a chunk = 40 pieces of 1 KB; wave w copies pieces 5 w .. 5 w + 4
+  // a chunk = 40 pieces of 1 KB; wave w copies pieces NP w .. NP w + NP - 1
   auto dma = [&](int chunk, int buf) {
 #pragma unroll
-    for (int n = 0; n < 5; ++n)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (GCD_AS3 void*)(smem + buf * LQ_CHUNK_BYTES + (wave * 5 + n) * 1024), 16,
-                                               lane * 16, chunk * LQ_CHUNK_BYTES + (wave * 5 + n) * 1024, 0, 0);
+    for (int n = 0; n < NP; ++n)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (GCD_AS3 void*)(smem + buf * LQ_CHUNK_BYTES + (wave * NP + n) * 1024), 16,
+                                               lane * 16, chunk * LQ_CHUNK_BYTES + (wave * NP + n) * 1024, 0, 0);
   };
   // stores are range-checked buffer stores, issued by every lane of every wave (rows past M carry an out-of-range offset):
   // the counted wait below relies on their number
@@ -150,12 +156,13 @@ __global__ __launch_bounds__(LQ_WAVES * 64) void lnqkv_kernel(const LnQkvK p) {
     };
     // PIPE: the results of chunk c - 1 (second accumulator set) are converted and stored in the middle of chunk c's MFMAs
     auto chunk = [&](int c, f32x4 (&acc)[4][LQ_T], const f32x4 (&prev)[4][LQ_T], bool prev_valid) {
-      // chunk `it` was requested one iteration ago, in front of that iteration's 2 LQ_T stores: "at most the newest 4 memory
+      // chunk `it` was requested one iteration ago, in front of that iteration's 2 LQ_T stores: "at most the newest 2 LQ_T memory
       // operations outstanding" = its pieces have landed (loads return in order, stores share the counter).  (PIPE: a tile's
       // first iteration issues no stores, so its second one waits for everything.)  After the barrier every wave's pieces
       // are in and every wave is past its reads of the other buffer.
       if (PIPE && c == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if constexpr (LQ_T == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (c + 1 < p.nchunks) dma(c + 1, (it + 1) & 1);
       else if (has_next) dma(0, (it + 1) & 1);
@@ -219,7 +226,9 @@ __global__ void lnqkv_pack_kernel(const f16* __restrict__ W, f16* __restrict__ W
   *(f16x8*)(Wp + (int64_t)idx * 8) = v;
 }
 
-GcdPerDeviceOnce g_lq_once, g_lq_once_p;
+#ifndef LQ_DEFAULT_FORM
+#define LQ_DEFAULT_FORM 0
+#endif
 
 int lq_cu_count() {
   int d = 0, n = 0;
@@ -267,14 +276,23 @@ extern "C" int gcd_lnqkv_f16(const float* x32, int64_t ldx32, const float* gamma
   k.nchunks = N / 64;
   k.sched = sched;
   const int ntiles = (M + LQ_TILE - 1) / LQ_TILE;
-  static const int pipe = getenv("GCD_LNQKV_PIPE") ? atoi(getenv("GCD_LNQKV_PIPE")) : 0;      // (development: A/B of the two forms)
-  if (pipe) {
-    GCD_CHECK_HIP(g_lq_once_p.opt_in((const void*)lnqkv_kernel<true>, LQ_SMEM));
-    hipLaunchKernelGGL(lnqkv_kernel<true>, dim3(std::min(ntiles, lq_cu_count())), dim3(LQ_WAVES * 64), LQ_SMEM, (hipStream_t)stream, k);
-  } else {
-    GCD_CHECK_HIP(g_lq_once.opt_in((const void*)lnqkv_kernel<false>, LQ_SMEM));
-    hipLaunchKernelGGL(lnqkv_kernel<false>, dim3(std::min(ntiles, lq_cu_count())), dim3(LQ_WAVES * 64), LQ_SMEM, (hipStream_t)stream, k);
+  // (development: A/B of the forms — bit 0: a chunk's stores under the next chunk's MFMAs; bit 1: 4 waves x 64 tokens instead
+  //  of 8 waves x 32)
+  static const int form = getenv("GCD_LNQKV_FORM") ? atoi(getenv("GCD_LNQKV_FORM")) : LQ_DEFAULT_FORM;
+  const dim3 grid(std::min(ntiles, lq_cu_count()));
+#define LQ_LAUNCH(W, T, P)                                                                                        \
+  do {                                                                                                            \
+    static GcdPerDeviceOnce once;                                                                                 \
+    GCD_CHECK_HIP(once.opt_in((const void*)lnqkv_kernel<W, T, P>, LQ_SMEM));                                      \
+    hipLaunchKernelGGL((lnqkv_kernel<W, T, P>), grid, dim3(W * 64), LQ_SMEM, (hipStream_t)stream, k);             \
+  } while (0)
+  switch (form & 3) {
+    case 0: LQ_LAUNCH(8, 2, false); break;
+    case 1: LQ_LAUNCH(8, 2, true); break;
+    case 2: LQ_LAUNCH(4, 4, false); break;
+    default: LQ_LAUNCH(4, 4, true); break;
   }
+#undef LQ_LAUNCH
   GCD_CHECK_LAUNCH();
   return 0;
 }

@@ -30,6 +30,8 @@ python tools/pmc_gemm_shapes.py $OUT/launches.json $F $W $H > $OUT/gemm_shape_tr
     -d $OUT/pmc_sq2 -o p -- python $ROOT/bench.py --steps 1 --warmup 1 --repeats 1 --no-cpu-baseline > $OUT/pmc_sq2.log 2>&1)
 (cd tools && python pmc_sq2.py $(find $OUT/pmc_sq2 -name "*counter_collection.csv" | head -1) > $OUT/sq_valu_mix.txt)
 tools/gemm_bench full 5 > $OUT/gemm_bench_rows.txt 2>&1
+# the fine-tune step through the same bench.py the driver runs (bf16 + fp16, C-ABI calls, cfg4 golden parity)
+python bench.py --train > $OUT/bench_train.json 2> $OUT/bench_train.err
 # the fine-tune step (round 5: planned engine by default; the autograd engine and forced checkpointing beside it)
 for dt in fp16 bf16; do python tools/train_step_bench.py --steps 4 --dtype $dt > $OUT/train_step_$dt.json 2>/dev/null; done
 python tools/train_step_bench.py --steps 4 --checkpoint on > $OUT/train_step_fp16_checkpointed.json 2>/dev/null

@@ -1,6 +1,6 @@
 """tools/lnqkv_bench.py — LayerNorm + q | k | v at the 72 x 128 level (M = 258 048 tokens, C = 320, N = 960): the one-launch
 kernel of gcd_amd/csrc/lnqkv.hip against gcd_layernorm_f16 + gcd_gemm_f16, HIP-event time per launch (caches flushed between
-launches by a 1 GB fill).  GCD_LNQKV_PIPE=1 selects the form that stores a chunk under the next chunk's MFMAs."""
+launches by a 1 GB fill).  GCD_LNQKV_FORM=0..3 selects the kernel form (bit 0: stores under the next chunk, bit 1: 4 waves x 64 tokens)."""
 import sys
 from pathlib import Path
 
