@@ -610,7 +610,7 @@ def main():
                          "unit": "TFLOP/s", "frac": round(gemm_tflops / PEAK_MFMA_TFLOPS, 4),
                          "traffic": traffic, "traffic_unit": "bytes per launch (fabric-side: HBM + Infinity Cache)",
                          "traffic_profile": traffic_note, "sources_digest": sources_digest(),
-                         "kernel": "gemm_p8_kernel (+ gemm_pp_kernel, gemm_f16_kernel for the shapes it does not take; MFMA implicit-GEMM family: Linear, Conv2d 3x3/1x1, Conv3d (3,1,1))",
+                         "kernel": "gemm_p8_kernel (+ gemm_pp_kernel, gemm_f16_kernel for the shapes it does not take; ff_fused_kernel = LayerNorm + FeedForward and lnqkv_kernel = LayerNorm + q|k|v at C = 320, conv3x3_narrow_kernel = the output head; MFMA implicit-GEMM family: Linear, Conv2d 3x3/1x1, Conv3d (3,1,1))",
                          "launches_per_step": gk["launches"],
                          "algorithmic_tflop_per_step": round(gk["flops"] / 1e12, 3),
                          "kernel_ms_per_step": round(gk["ms"], 3)},

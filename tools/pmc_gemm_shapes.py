@@ -22,7 +22,8 @@ import sys
 from collections import OrderedDict, defaultdict
 
 csv.field_size_limit(1 << 30)
-GEMM_KEYS = ("gemm_p8_kernel", "gemm_p8x_kernel", "gemm_pp_kernel", "gemm_f16_kernel", "splitk_reduce_kernel")
+GEMM_KEYS = ("gemm_p8_kernel", "gemm_p8x_kernel", "gemm_pp_kernel", "gemm_f16_kernel", "splitk_reduce_kernel",
+             "ff_fused_kernel", "lnqkv_kernel", "conv3x3_narrow_kernel")      # = pmc_traffic.FAMILIES["gemm"]
 
 
 def dispatches(path):
@@ -78,6 +79,10 @@ def main():
         rows_in = M * (stride * stride) // (4 if up else 1) if mode == 1 else M
         a_bytes = rows_in * cin * 2 if mode != 0 else M * K * 2
         alg_r = (a_bytes + N * K * 2 + nres * M * N * 4) / 1e6
+        if g["rec"].get("fused_ff"):      # LayerNorm + FeedForward in one launch: the fp32 rows once, the weights, a second stream
+            alg_r = (M * 320 * 4 + 320 * 3840 * 2 + (nres - 1) * M * 320 * 4) / 1e6
+        elif g["rec"].get("fused_ln"):    # LayerNorm + q|k|v: the fp32 rows once, the weights
+            alg_r = (M * 320 * 4 + N * 320 * 2) / 1e6
         alg_w = M * (N // 2 if ok == 2 else N) * (4 if ok == 0 else 2) / 1e6
         f2, w = 2 * g["fetch"] / n, g["write"] / n
         us = g["ms"] / n * 1e3

@@ -23,7 +23,10 @@ from collections import defaultdict
 csv.field_size_limit(1 << 30)
 
 FAMILIES = [
-    ("gemm", ("gemm_p8_kernel", "gemm_p8x_kernel", "gemm_pp_kernel", "gemm_f16_kernel", "splitk_reduce_kernel")),
+    # what bench.py times as the GEMM family (ops._Timed("gemm")): the tile kernels and, from round 6, the one-launch
+    # LayerNorm + FeedForward, LayerNorm + q|k|v and the output head
+    ("gemm", ("gemm_p8_kernel", "gemm_p8x_kernel", "gemm_pp_kernel", "gemm_f16_kernel", "splitk_reduce_kernel",
+              "ff_fused_kernel", "lnqkv_kernel", "conv3x3_narrow_kernel")),
     ("attn_spatial", ("attn_spatial",)),
     ("attn_temporal", ("attn_temporal",)),
     ("groupnorm", ("gn_stats", "gn_apply")),
