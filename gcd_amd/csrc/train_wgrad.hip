@@ -16,7 +16,8 @@
 // (tools/gemm_tr_probe.cpp, profiles/r04v_gemm_tr_probe.txt: 185-600 TF/s on the step's shapes, untuned).
 //
 // Kernel (train_wgrad_kernel.h): 128 (n) x 128 (k) output tile per workgroup, 4 waves of 64 x 64 (16 accumulators of
-// v_mfma_f32_16x16x32), 32 or 64 tokens per step, operands through registers into a double-buffered LDS tile (272-byte
+// v_mfma_f32_16x16x32) — or, round 6, 160 x 160 with 4 waves of 80 x 80 where that removes padded work (every width of the
+// UNet is a multiple of 320 = 2.5 x 128; gcd_wgrad::tile_of) — 32 or 64 tokens per step, operands through registers into a double-buffered LDS tile (272-byte
 // rows), the token axis split over S workgroups whose fp32 partial outputs a second launch folds (no atomics).  Untuned: no
 // LDS-DMA, no swizzle, one barrier per 16 / 32 MFMAs per wave.
 #include <hip/hip_runtime.h>
@@ -59,6 +60,8 @@ static int wgrad_tm(int64_t M, int N, int K) {
     return (v == 32 || v == 64) ? v : 0;
   }();
   if (forced) return forced;
+  // the 160 x 160 tile (round 6) takes 86 KB of LDS at 64 tokens per step — one workgroup per CU; at 32 it is 43 KB
+  if (gcd_wgrad::tile_of(N, K) == 160) return 32;
   return (M >= 32768 && (int64_t)N * K >= 400000) ? 64 : GCD_WGRAD_TM_DEFAULT;
 }
 

@@ -11,24 +11,7 @@ python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/trace -o p -- python $ROOT/bench.py --steps 5 --warmup 2 \
     --repeats 1 --no-cpu-baseline > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err)
 python tools/rocpd_stats.py $(find $OUT/trace -name "*_results.db" | head -1) --steps 8 > $OUT/kernel_stats.txt
-for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
-  D=$OUT/pmc_${C%% *}
-  (cd /tmp && rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -o p -- python $ROOT/bench.py --steps 1 \
-      --warmup 1 --repeats 1 --no-cpu-baseline --dump-profile $OUT/launches.json > $D.log 2>&1)
-done
-F=$(find $OUT/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
-W=$(find $OUT/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-H=$(find $OUT/pmc_TCC_HIT_sum -name "*counter_collection.csv" | head -1)
-python tools/pmc_traffic.py $F $W --json $OUT/hbm_traffic.json --source profiles/${TAG}_hbm_traffic.txt > $OUT/hbm_traffic.txt
-python tools/pmc_gemm_shapes.py $OUT/launches.json $F $W $H > $OUT/gemm_shape_traffic.txt
-(cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU \
-    SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
-    -d $OUT/pmc_sq -o p -- python $ROOT/bench.py --steps 1 --warmup 1 --repeats 1 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1)
-(cd tools && python pmc_sq.py $(find $OUT/pmc_sq -name "*counter_collection.csv" | head -1) > $OUT/sq_counters.txt)
-(cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_MFMA \
-    SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_LDS --kernel-trace --output-format csv \
-    -d $OUT/pmc_sq2 -o p -- python $ROOT/bench.py --steps 1 --warmup 1 --repeats 1 --no-cpu-baseline > $OUT/pmc_sq2.log 2>&1)
-(cd tools && python pmc_sq2.py $(find $OUT/pmc_sq2 -name "*counter_collection.csv" | head -1) > $OUT/sq_valu_mix.txt)
+bash tools/collect_pmc.sh $TAG
 tools/gemm_bench full 5 > $OUT/gemm_bench_rows.txt 2>&1
 # the fine-tune step through the same bench.py the driver runs (bf16 + fp16, C-ABI calls, cfg4 golden parity)
 python bench.py --train > $OUT/bench_train.json 2> $OUT/bench_train.err
@@ -46,7 +29,7 @@ python tools/rocpd_stats.py $(find $OUT/trace_train -name "*_results.db" | head 
 for e in planned autograd; do bash tools/train_profile.sh $TAG/tp_$e $e > /dev/null 2>&1; cp $OUT/tp_$e/launches_per_step_$e.txt $OUT/; done
 cat $OUT/launches_per_step_*.txt
 # keep the summaries only: gpurun merges at most 64 MiB back
-rm -rf $OUT/trace $OUT/trace_train $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_TCC_HIT_sum $OUT/pmc_sq $OUT/pmc_sq2
+rm -rf $OUT/trace $OUT/trace_train
 du -sh $ROOT/gpurun_out
 ls -la $OUT
 # round 4: the CPU path timed at the metric's own shape beside the GPU number (one oracle step at 14x72x128, minutes)

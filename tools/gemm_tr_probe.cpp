@@ -123,6 +123,11 @@ int main() {
   bad += run<false, 64>(2080, 200, 328, 1, true);
   bad += run<true, 32>(4100, 320, 640, 1, true);
   bad += run<true, 64>(4100, 320, 640, 1, true);
+  // (round 6) the 160 x 160 tile (gcd_wgrad::tile_of: N and K multiples of 160, one of them not of 128; GCD_WGRAD_TILE=128
+  // forces the old tile for the A/B): ragged token counts, both step sizes, 4 x 6 and 2 x 2 tiles
+  bad += run<false, 32>(4100, 640, 960, 1, true);
+  bad += run<false, 64>(3001, 320, 320, 1, true);
+  bad += run<true, 32>(2999, 960, 320, 1, true);
   // the fine-tune step's wgrad shapes at cfg4 (M = frames x pixels of a level), 32 vs 64 tokens per step
   const int shapes[][3] = {{43008, 320, 320}, {43008, 320, 1280}, {43008, 2560, 320}, {43008, 320, 2880},
                            {10752, 640, 640}, {10752, 640, 5760}, {2688, 1280, 1280}, {2688, 1280, 11520}};
