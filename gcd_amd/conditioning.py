@@ -15,21 +15,47 @@ import torch.nn as nn
 from . import ops
 
 
-def _project(feats: torch.Tensor, proj: nn.Linear) -> torch.Tensor:
-    """feats [n, k] fp32 (cuda) -> proj(feats) via gcd_linear_smallm_f32 (K padded to 4, rows in
-    chunks of 32)."""
-    ops._need_gpu(feats, proj.weight)
+def _project_hip(feats: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """feats [n, k] fp32 (cuda) -> feats @ weight^T + bias via gcd_linear_smallm_f32 (K padded to 4, rows in chunks of 32)."""
     n, k = feats.shape
     kp = (k + 3) // 4 * 4
     x = torch.zeros(n, kp, device=feats.device, dtype=torch.float32)
     x[:, :k] = feats
-    w = torch.zeros(proj.out_features, kp, device=feats.device, dtype=torch.float32)
-    w[:, :k] = proj.weight.detach().float()
-    b = proj.bias.detach().float().contiguous()
-    out = torch.empty(n, proj.out_features, device=feats.device, dtype=torch.float32)
+    w = torch.zeros(weight.shape[0], kp, device=feats.device, dtype=torch.float32)
+    w[:, :k] = weight.detach().float()
+    b = bias.detach().float().contiguous()
+    out = torch.empty(n, weight.shape[0], device=feats.device, dtype=torch.float32)
     for r0 in range(0, n, 32):
         ops.linear_smallm(x[r0:r0 + 32], w, b, out[r0:r0 + 32])
     return out
+
+
+class _ProjectFn(torch.autograd.Function):
+    """The embedder's projection as a graph node: the reference trains SphericalEmbedder.proj (`is_trainable: True` in the
+    Kubric configs; encoders/modules.py:84-208 leaves trainable embedders in the graph), so proj(feats) must hand its
+    weight and bias a gradient.  Forward on the HIP kernel; the backward of a [n <= a few dozen, k <= 16] x [128, k] product
+    (a few kFLOP, once per step) is two torch matmuls on the device."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, bias):
+        ctx.save_for_backward(feats, weight)
+        return _project_hip(feats, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        feats, weight = ctx.saved_tensors
+        dy = dy.float()
+        d_feats = dy @ weight.float() if ctx.needs_input_grad[0] else None
+        d_w = (dy.t() @ feats.float()).to(weight.dtype) if ctx.needs_input_grad[1] else None
+        d_b = dy.sum(0).to(weight.dtype) if ctx.needs_input_grad[2] else None
+        return d_feats, d_w, d_b
+
+
+def _project(feats: torch.Tensor, proj: nn.Linear) -> torch.Tensor:
+    ops._need_gpu(feats, proj.weight)
+    if torch.is_grad_enabled() and (proj.weight.requires_grad or feats.requires_grad):
+        return _ProjectFn.apply(feats, proj.weight, proj.bias)
+    return _project_hip(feats, proj.weight, proj.bias)
 
 
 class AbstractEmbModel(nn.Module):

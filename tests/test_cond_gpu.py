@@ -62,6 +62,33 @@ def test_embedders_vs_reference_golden(gpu, g):
         sph(g["trajectories"]["direct"]["rel"])
 
 
+def test_trainable_pose_embedder_receives_gradients(gpu, g):
+    """The Kubric configs train SphericalEmbedder.proj (`is_trainable: True`): the embedding must stay in the autograd graph
+    (the projection used to run on detached weights, so a pose-embedder fine-tune would silently never learn).
+    Forward = the HIP kernel as before; d proj.weight / d proj.bias against torch's own Linear on the same features."""
+    cond = _kubric_conditioner(gpu)
+    sph = cond.embedders[5]
+    sph.proj.weight.requires_grad_(True)
+    sph.proj.bias.requires_grad_(True)
+    t = next(iter(g["trajectories"].values()))["rel"].to(gpu)
+    out = sph(t)
+    assert out.requires_grad
+    wsum = torch.randn(out.shape, device=gpu, generator=torch.Generator(device=gpu).manual_seed(3))
+    (out * wsum).sum().backward()
+    gw, gb = sph.proj.weight.grad.clone(), sph.proj.bias.grad.clone()
+    # torch reference: the features proj() is applied to = the pseudo-inverse of the forward through a second Linear
+    ref = torch.nn.Linear(sph.proj.in_features, sph.proj.out_features).to(gpu)
+    ref.load_state_dict(sph.proj.state_dict())
+    feats = torch.linalg.lstsq(sph.proj.weight.detach().double(),
+                               (out.detach().double() - sph.proj.bias.detach().double()).reshape(-1, out.shape[-1]).t()).solution
+    o2 = ref(feats.t().float()).reshape(out.shape)
+    assert rel_l2(o2, out.detach()) < 1e-5
+    (o2 * wsum).sum().backward()
+    assert rel_l2(gw, ref.weight.grad) < 1e-4 and rel_l2(gb, ref.bias.grad) < 1e-5
+    with torch.no_grad():                      # inference: no graph node, same values
+        assert torch.equal(sph(t), out.detach())
+
+
 def test_general_conditioner_vs_reference_golden(gpu, g):
     cond = _kubric_conditioner(gpu)
     b = _batch(gpu, g)
