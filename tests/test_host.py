@@ -324,3 +324,29 @@ def test_fused_feedforward_generated_code_keeps_its_hazard_distances():
     r = subprocess.run([sys.executable, str(root / "tools" / "ff_isa_audit.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("0 finding(s)") == 6, r.stdout          # three epilogue forms x (plain, LayerNorm) the library carries
+
+
+def test_round6_kernels_compile_without_spills():
+    """lnqkv.hip, conv_narrow.hip and the wide fp32 Linear hold their operands in registers across long unrolled loops; hipcc's
+    scheduling of them is fragile (left alone it hoisted the 40 LayerNorm-affine reads of lnqkv_kernel and spilled 250
+    registers into the hot prologue — the source pins the pass order).  A spill there is a silent 2x: check the code
+    object metadata of what the library is built from.  (hipcc cross-compiles without a GPU: ~40 s.)"""
+    import re
+    import subprocess
+    import tempfile
+    from pathlib import Path
+    from gcd_amd.csrc import build as B
+    wanted = {"lnqkv.hip": ("lnqkv_kernel",), "conv_narrow.hip": ("conv3x3_narrow_kernel",),
+              "elementwise.hip": ("linear_smallm_mfma_kernel",)}
+    with tempfile.TemporaryDirectory() as td:
+        for src, kernels in wanted.items():
+            out = Path(td) / (src + ".s")
+            subprocess.check_call([B._hipcc(), *B.FLAGS, *B.EXTRA_FLAGS.get(src, []), "--cuda-device-only", "-S",
+                                   str(B.CSRC / src), "-o", str(out)], stderr=subprocess.DEVNULL)
+            text = out.read_text()
+            found = 0
+            for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text):
+                if any(k in m.group(1) for k in kernels):
+                    found += 1
+                    assert int(m.group(2)) == 0, f"{m.group(1)} spills {m.group(2)} registers"
+            assert found >= 1, f"no kernel of {kernels} found in {src}"
