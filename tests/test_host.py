@@ -36,7 +36,8 @@ def test_train_library_exports_every_declared_symbol():
     assert declared == set(_lib.TRAIN_SIGNATURES), (declared ^ set(_lib.TRAIN_SIGNATURES))
     lib = _lib.load_train()
     assert lib.gcd_train_abi_version() == _lib.TRAIN_ABI_VERSION
-    assert lib.gcd_wgrad_tr_scratch_floats(43008, 320, 1280) == 34 * 320 * 1280      # 3 x 10 tiles -> 34 token slices
+    assert lib.gcd_wgrad_tr_scratch_floats(43008, 320, 1280) == 64 * 320 * 1280      # 2 x 8 tiles of 160 -> 64 token slices
+    assert lib.gcd_wgrad_tr_scratch_floats(10752, 640, 640) == 40 * 640 * 640        # 5 x 5 tiles of 128 -> 40 token slices
     assert lib.gcd_wgrad_tr_f16(16, 320, 16, 1280, 100, 321, 1280, 0, 16, 1280, 16, 1 << 30, None) != 0
     assert b"multiples of 8" in lib.gcd_train_last_error()
 
